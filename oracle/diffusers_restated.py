@@ -1,0 +1,329 @@
+"""Restatement of the `diffusers` arithmetic the reference's hot path calls.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  `diffusers` (requirements.txt:26,
+``diffusers>=0.30.1``, unpinned) is a third-party dependency that is NOT vendored
+in /root/reference and NOT installed in this image, so every function here is a
+restatement of its *published* algorithm -> **parity unpinned**; the call sites in
+the reference that anchor each function are cited.  Known-answer tests:
+tests/test_oracle_kat.py.
+
+All functions take / return float32 working tensors; `p` is an oracle.prec.Prec.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .prec import Prec
+
+
+# ---------------------------------------------------------------------------
+# embeddings  (call sites: reference models/crosstransformer3d.py:531-534,724-732)
+# ---------------------------------------------------------------------------
+def timesteps_proj(timesteps: torch.Tensor, num_channels: int, flip_sin_to_cos: bool = True,
+                   downscale_freq_shift: float = 0.0, scale: float = 1.0,
+                   max_period: int = 10000) -> torch.Tensor:
+    """diffusers `Timesteps` / get_timestep_embedding: fp32 sinusoidal embedding."""
+    assert timesteps.ndim == 1
+    half = num_channels // 2
+    exponent = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32)
+    exponent = exponent / (half - downscale_freq_shift)
+    emb = torch.exp(exponent)
+    emb = timesteps[:, None].float() * emb[None, :]
+    emb = scale * emb
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    if num_channels % 2 == 1:
+        emb = F.pad(emb, (0, 1, 0, 0))
+    return emb
+
+
+def timestep_embedding(p: Prec, sd: dict, prefix: str, t_emb: torch.Tensor) -> torch.Tensor:
+    """diffusers `TimestepEmbedding(in, time_embed_dim, "silu")`: linear_2(silu(linear_1(x)))."""
+    x = p.linear(t_emb, sd[prefix + "linear_1.weight"], sd[prefix + "linear_1.bias"])
+    x = p.r(F.silu(x))
+    return p.linear(x, sd[prefix + "linear_2.weight"], sd[prefix + "linear_2.bias"])
+
+
+# ---------------------------------------------------------------------------
+# normalisation  (call sites: crosstransformer3d.py:195-197,211-213,556-562)
+# ---------------------------------------------------------------------------
+def layer_norm_zero(p: Prec, sd: dict, prefix: str, hidden, encoder, temb, eps: float):
+    """diffusers `CogVideoXLayerNormZero.forward`.
+
+    s = linear(silu(temb)); (shift, scale, gate, e_shift, e_scale, e_gate) = s.chunk(6, 1)
+    video rows: LN(x)*(1+scale)+shift ; text rows: LN(x)*(1+e_scale)+e_shift ; returns gates [B,1,D].
+    """
+    s = p.linear(p.r(F.silu(temb)), sd[prefix + "linear.weight"], sd[prefix + "linear.bias"])
+    shift, scale, gate, e_shift, e_scale, e_gate = s.chunk(6, dim=1)
+    w, b = sd.get(prefix + "norm.weight"), sd.get(prefix + "norm.bias")
+
+    def mod(x, sc, sh):
+        n = p.layer_norm(x, w, b, eps)                       # per-op point in the reference
+        y = p.r(n * p.r(1 + sc)[:, None, :])
+        return p.R(y + sh[:, None, :])                       # contract point: fused LN+modulate output
+
+    return mod(hidden, scale, shift), mod(encoder, e_scale, e_shift), gate[:, None, :], e_gate[:, None, :]
+
+
+def ada_layer_norm(p: Prec, sd: dict, prefix: str, x, temb, eps: float):
+    """diffusers `AdaLayerNorm(chunk_dim=1)`: **shift first**: shift, scale = t.chunk(2, 1)."""
+    t = p.linear(p.r(F.silu(temb)), sd[prefix + "linear.weight"], sd[prefix + "linear.bias"])
+    shift, scale = t.chunk(2, dim=1)
+    n = p.layer_norm(x, sd.get(prefix + "norm.weight"), sd.get(prefix + "norm.bias"), eps)
+    y = p.r(n * p.r(1 + scale)[:, None, :])
+    return p.R(y + shift[:, None, :])
+
+
+# ---------------------------------------------------------------------------
+# rotary embedding (call sites: pipeline_trajectorycrafter.py:616-649; processor below)
+# ---------------------------------------------------------------------------
+def get_3d_rotary_pos_embed(embed_dim: int, crops_coords, grid_size, temporal_size: int,
+                            theta: float = 10000.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """diffusers `get_3d_rotary_pos_embed(..., use_real=True)` -> (cos, sin) each [T*H*W, embed_dim] fp32."""
+    start, stop = crops_coords
+    gh, gw = grid_size
+    grid_h = np.linspace(start[0], stop[0], gh, endpoint=False, dtype=np.float32)
+    grid_w = np.linspace(start[1], stop[1], gw, endpoint=False, dtype=np.float32)
+    grid_t = np.linspace(0, temporal_size, temporal_size, endpoint=False, dtype=np.float32)
+
+    dim_t = embed_dim // 4
+    dim_h = embed_dim // 8 * 3
+    dim_w = embed_dim // 8 * 3
+
+    def axis(pos, dim):
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float32)[: dim // 2] / dim))
+        ang = torch.outer(torch.from_numpy(pos).float(), freqs)
+        return ang.repeat_interleave(2, dim=-1)
+
+    ft, fh, fw = axis(grid_t, dim_t), axis(grid_h, dim_h), axis(grid_w, dim_w)
+    T = temporal_size
+    ft = ft[:, None, None, :].expand(T, gh, gw, dim_t)
+    fh = fh[None, :, None, :].expand(T, gh, gw, dim_h)
+    fw = fw[None, None, :, :].expand(T, gh, gw, dim_w)
+    freqs = torch.cat([ft, fh, fw], dim=-1).reshape(T * gh * gw, -1)
+    return freqs.cos().contiguous(), freqs.sin().contiguous()
+
+
+def apply_rotary_emb(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """diffusers `apply_rotary_emb(x, (cos, sin), use_real=True, use_real_unbind_dim=-1)`; x [B,H,S,D] fp32."""
+    cos = cos[None, None]
+    sin = sin[None, None]
+    xr, xi = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    rot = torch.stack([-xi, xr], dim=-1).flatten(3)
+    return x.float() * cos + rot.float() * sin
+
+
+# ---------------------------------------------------------------------------
+# attention (call site: crosstransformer3d.py:199-208, 239-243)
+# ---------------------------------------------------------------------------
+def sdpa(p: Prec, q, k, v, scale: float) -> torch.Tensor:
+    """softmax(q k^T * scale) v with fp32 scores/softmax and P rounded to the activation dtype
+    before PV (flash-attention practice; SURVEY §8c rounding contract)."""
+    s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * scale
+    pr = torch.softmax(s, dim=-1)
+    pr = p.R(pr)
+    return torch.matmul(pr, v.float())
+
+
+def cogvideox_attention(p: Prec, sd: dict, prefix: str, hidden, encoder, heads: int,
+                        rotary: Optional[Tuple[torch.Tensor, torch.Tensor]], eps: float = 1e-6):
+    """diffusers `Attention` + `CogVideoXAttnProcessor2_0.__call__`; returns (video, text)."""
+    text_len = encoder.shape[1]
+    h = torch.cat([encoder, hidden], dim=1)
+    B, S, D = h.shape
+    dh = D // heads
+
+    def proj(name):
+        y = p.linear(h, sd[prefix + name + ".weight"], sd.get(prefix + name + ".bias"))
+        return y.view(B, S, heads, dh).transpose(1, 2)
+
+    q, k, v = proj("to_q"), proj("to_k"), proj("to_v")
+    q = p.layer_norm(q, sd[prefix + "norm_q.weight"], sd[prefix + "norm_q.bias"], eps)
+    k = p.layer_norm(k, sd[prefix + "norm_k.weight"], sd[prefix + "norm_k.bias"], eps)
+    if rotary is not None:
+        cos, sin = rotary
+        q = torch.cat([q[:, :, :text_len], apply_rotary_emb(q[:, :, text_len:], cos, sin)], dim=2)
+        k = torch.cat([k[:, :, :text_len], apply_rotary_emb(k[:, :, text_len:], cos, sin)], dim=2)
+    q, k = p.R(q), p.R(k)                                    # contract: fused qk-LN+RoPE output
+    o = sdpa(p, q, k, v, scale=dh ** -0.5)
+    o = p.R(o).transpose(1, 2).reshape(B, S, D)              # contract: attention output
+    o = p.linear(o, sd[prefix + "to_out.0.weight"], sd.get(prefix + "to_out.0.bias"))
+    return o[:, text_len:], o[:, :text_len]
+
+
+def feed_forward(p: Prec, sd: dict, prefix: str, x):
+    """diffusers `FeedForward(activation_fn="gelu-approximate")`: net.0 = GELU(tanh) proj, net.2 = Linear."""
+    y = F.linear(x.float(), p.param(sd[prefix + "net.0.proj.weight"]), p.param(sd[prefix + "net.0.proj.bias"]))
+    y = p.r(y)                                               # reference rounds the GEMM output first
+    y = p.R(F.gelu(y, approximate="tanh"))                   # contract: fused bias+GELU output
+    return p.linear(y, sd[prefix + "net.2.weight"], sd[prefix + "net.2.bias"])
+
+
+# ---------------------------------------------------------------------------
+# VAE helpers (call sites: autoencoder_magvit.py:428,623,1197,1212)
+# ---------------------------------------------------------------------------
+def upsample3d_nearest(x: torch.Tensor, compress_time: bool) -> torch.Tensor:
+    """The interpolation half of diffusers `CogVideoXUpsample3D.forward` (x [B,C,T,H,W])."""
+    if compress_time:
+        T = x.shape[2]
+        if T > 1 and T % 2 == 1:
+            first, rest = x[:, :, 0], x[:, :, 1:]
+            first = F.interpolate(first, scale_factor=2.0)
+            rest = F.interpolate(rest, scale_factor=2.0)
+            return torch.cat([first[:, :, None], rest], dim=2)
+        if T > 1:
+            return F.interpolate(x, scale_factor=2.0)
+        return F.interpolate(x.squeeze(2), scale_factor=2.0)[:, :, None]
+    b, c, t, h, w = x.shape
+    y = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+    y = F.interpolate(y, scale_factor=2.0)
+    return y.reshape(b, t, c, 2 * h, 2 * w).permute(0, 2, 1, 3, 4)
+
+
+def conv2d_per_frame(p: Prec, x, w, b, stride: int, padding: int):
+    bsz, c, t, h, wd = x.shape
+    y = x.permute(0, 2, 1, 3, 4).reshape(bsz * t, c, h, wd)
+    y = p.R(F.conv2d(y.float(), p.param(w), p.param(b), stride=stride, padding=padding))
+    return y.reshape(bsz, t, *y.shape[1:]).permute(0, 2, 1, 3, 4)
+
+
+def upsample3d(p: Prec, sd: dict, prefix: str, x, compress_time: bool):
+    """diffusers `CogVideoXUpsample3D(C, C, padding=1, compress_time)`: nearest x2 then per-frame Conv2d 3x3."""
+    y = upsample3d_nearest(x, compress_time)
+    return conv2d_per_frame(p, y, sd[prefix + "conv.weight"], sd[prefix + "conv.bias"], 1, 1)
+
+
+def downsample3d(p: Prec, sd: dict, prefix: str, x, compress_time: bool):
+    """diffusers `CogVideoXDownsample3D(C, C, padding=0, compress_time)` (encoder only)."""
+    if compress_time:
+        b, c, t, h, w = x.shape
+        y = x.permute(0, 3, 4, 1, 2).reshape(b * h * w, c, t)
+        if t % 2 == 1:
+            first, rest = y[..., 0], y[..., 1:]
+            if rest.shape[-1] > 0:
+                rest = F.avg_pool1d(rest, kernel_size=2, stride=2)
+            y = torch.cat([first[..., None], rest], dim=-1)
+        else:
+            y = F.avg_pool1d(y, kernel_size=2, stride=2)
+        y = p.R(y)
+        x = y.reshape(b, h, w, c, y.shape[-1]).permute(0, 3, 4, 1, 2)
+    x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0)
+    return conv2d_per_frame(p, x, sd[prefix + "conv.weight"], sd[prefix + "conv.bias"], 2, 0)
+
+
+class DiagonalGaussian:
+    """diffusers `DiagonalGaussianDistribution`."""
+
+    def __init__(self, params: torch.Tensor):
+        self.mean, self.logvar = torch.chunk(params, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator=None):
+        noise = torch.randn(self.mean.shape, generator=generator, dtype=self.mean.dtype)
+        return self.mean + self.std * noise
+
+    def mode(self):
+        return self.mean
+
+
+# ---------------------------------------------------------------------------
+# image processors (call sites: pipeline_trajectorycrafter.py:237-243,864,876,952)
+# ---------------------------------------------------------------------------
+def vae_image_preprocess(x: torch.Tensor, height: int, width: int, do_normalize: bool = True,
+                         do_binarize: bool = False) -> torch.Tensor:
+    """diffusers `VaeImageProcessor.preprocess` for 4-D tensor input [N,C,H,W]."""
+    if x.shape[-2:] != (height, width):
+        x = F.interpolate(x, size=(height, width))
+    x = x.clone()
+    if do_normalize and x.min() >= 0:
+        x = 2.0 * x - 1.0
+    if do_binarize:
+        x[x < 0.5] = 0
+        x[x >= 0.5] = 1
+    return x
+
+
+# ---------------------------------------------------------------------------
+# scheduler (selected demo.py:647-657; used pipeline_trajectorycrafter.py:846,1164-1167)
+# ---------------------------------------------------------------------------
+class DDIMScheduler:
+    """diffusers `DDIMScheduler` restricted to the configuration CogVideoX-Fun ships
+    (recalled, the checkpoint's scheduler_config.json is absent -> unverified)."""
+
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012,
+                 beta_schedule="scaled_linear", prediction_type="v_prediction",
+                 timestep_spacing="trailing", rescale_betas_zero_snr=True, set_alpha_to_one=True,
+                 steps_offset=0, clip_sample=False):
+        assert beta_schedule == "scaled_linear" and not clip_sample
+        self.num_train_timesteps = num_train_timesteps
+        self.prediction_type = prediction_type
+        self.timestep_spacing = timestep_spacing
+        self.steps_offset = steps_offset
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        if rescale_betas_zero_snr:
+            alphas = 1.0 - betas
+            abar_sqrt = torch.cumprod(alphas, dim=0).sqrt()
+            a0, aT = abar_sqrt[0].clone(), abar_sqrt[-1].clone()
+            abar_sqrt = (abar_sqrt - aT) * (a0 / (a0 - aT))
+            abar = abar_sqrt ** 2
+            alphas = torch.cat([abar[0:1], abar[1:] / abar[:-1]])
+            betas = 1 - alphas
+        self.betas = betas
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+        self.num_inference_steps = None
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        N = self.num_train_timesteps
+        if self.timestep_spacing == "trailing":
+            ts = np.round(np.arange(N, 0, -N / num_inference_steps)).astype(np.int64) - 1
+        elif self.timestep_spacing == "leading":
+            ts = (np.arange(0, num_inference_steps) * (N // num_inference_steps)).round()[::-1].copy().astype(np.int64)
+            ts += self.steps_offset
+        else:
+            raise ValueError(self.timestep_spacing)
+        self.timesteps = torch.from_numpy(ts)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def coeffs(self, timestep: int):
+        prev = timestep - self.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[timestep]
+        a_prev = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+        return a_t, a_prev
+
+    def step(self, p: Prec, model_output: torch.Tensor, timestep: int, sample: torch.Tensor, eta: float = 0.0):
+        """`DDIMScheduler.step` (eta = 0).  `model_output` fp32, `sample` in the activation dtype.
+
+        Type-promotion quirk reproduced: a 0-dim fp32 scalar times a bf16 tensor
+        stays bf16, so sqrt(a)*sample and sqrt(1-a)*sample are rounded to bf16 before they
+        meet the fp32 model output.
+        """
+        assert eta == 0.0
+        a_t, a_prev = self.coeffs(int(timestep))
+        b_t = 1 - a_t
+        sa, sb = a_t ** 0.5, b_t ** 0.5
+        s = sample.float()
+        if self.prediction_type == "v_prediction":
+            x0 = p.R(sa * s) - sb * model_output
+            eps = sa * model_output + p.R(sb * s)
+        elif self.prediction_type == "epsilon":
+            x0 = (s - sb * model_output) / sa
+            eps = model_output
+        else:
+            raise ValueError(self.prediction_type)
+        direction = (1 - a_prev) ** 0.5 * eps
+        return a_prev ** 0.5 * x0 + direction

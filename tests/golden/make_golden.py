@@ -1,0 +1,424 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own classes.
+
+Run ONLY in the build container (needs /root/reference; the GPU box never sees it):
+
+    python tests/golden/make_golden.py
+
+What is executed from the reference (imported, never copied): models/crosstransformer3d.py
+(CogVideoXPatchEmbed, RefPatchEmbed, CogVideoXBlock, PerceiverCrossAttention,
+CrossTransformer3DModel.forward), models/autoencoder_magvit.py (every VAE class,
+encode/_decode) and models/pipeline_trajectorycrafter.py (TrajCrafter_Pipeline.__call__).
+
+`diffusers` is not installed.  The names the reference imports from it are provided
+here as *scaffolding*: config/model mixins, output dataclasses and thin nn.Module shells whose
+arithmetic is oracle/diffusers_restated.py.  Consequently the fixtures pin the reference's own
+code against the oracle's restatement of it; the diffusers-resident arithmetic itself stays
+"parity unpinned" (covered by analytic KATs in tests/test_oracle_kat.py).
+
+Fixtures are safetensors files: weights (bf16-representable, stored as bf16), inputs, outputs.
+"""
+from __future__ import annotations
+
+import inspect
+import os
+import sys
+import types
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import diffusers_restated as dr            # noqa: E402
+from oracle.prec import Prec                          # noqa: E402
+from trajectorycrafter_amd import init_weights as iw  # noqa: E402
+
+P32 = Prec("fp32")
+
+
+# --------------------------------------------------------------------------- scaffolding
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def register_to_config(init):
+    sig = inspect.signature(init)
+
+    def wrapped(self, *a, **kw):
+        ba = sig.bind(self, *a, **kw)
+        ba.apply_defaults()
+        cfg = _Cfg({k: v for k, v in ba.arguments.items() if k != "self"})
+        object.__setattr__(self, "_cfg", cfg)
+        init(self, *a, **kw)
+
+    return wrapped
+
+
+class ConfigMixin:
+    @property
+    def config(self):
+        return self._cfg
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        c = dict(config)
+        c.update(kw)
+        return cls(**{k: v for k, v in c.items() if k in inspect.signature(cls.__init__).parameters})
+
+
+class ModelMixin(nn.Module):
+    @property
+    def dtype(self):
+        ps = list(self.parameters())
+        return ps[0].dtype if ps else torch.float32
+
+    @property
+    def device(self):
+        ps = list(self.parameters())
+        return ps[0].device if ps else torch.device("cpu")
+
+
+class _Logger:
+    def __getattr__(self, _):
+        return lambda *a, **k: None
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _sd(module, prefix=""):
+    return {prefix + k: v for k, v in module.state_dict().items()}
+
+
+class Timesteps(nn.Module):
+    def __init__(self, num_channels, flip_sin_to_cos, downscale_freq_shift, scale=1):
+        super().__init__()
+        self.a = (num_channels, flip_sin_to_cos, downscale_freq_shift, scale)
+
+    def forward(self, t):
+        return dr.timesteps_proj(t, *self.a)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels, time_embed_dim, act_fn="silu"):
+        super().__init__()
+        assert act_fn == "silu"
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+    def forward(self, x, cond=None):
+        return dr.timestep_embedding(P32, _sd(self), "", x)
+
+
+class CogVideoXLayerNormZero(nn.Module):
+    def __init__(self, conditioning_dim, embedding_dim, elementwise_affine=True, eps=1e-5, bias=True):
+        super().__init__()
+        self.silu = nn.SiLU()
+        self.linear = nn.Linear(conditioning_dim, 6 * embedding_dim, bias=bias)
+        self.norm = nn.LayerNorm(embedding_dim, eps=eps, elementwise_affine=elementwise_affine)
+        self.eps = eps
+
+    def forward(self, hidden_states, encoder_hidden_states, temb):
+        return dr.layer_norm_zero(P32, _sd(self), "", hidden_states, encoder_hidden_states, temb, self.eps)
+
+
+class AdaLayerNorm(nn.Module):
+    def __init__(self, embedding_dim, output_dim, norm_elementwise_affine=True, norm_eps=1e-5, chunk_dim=0):
+        super().__init__()
+        assert chunk_dim == 1
+        self.silu = nn.SiLU()
+        self.linear = nn.Linear(embedding_dim, output_dim)
+        self.norm = nn.LayerNorm(output_dim // 2, norm_eps, norm_elementwise_affine)
+        self.eps = norm_eps
+
+    def forward(self, x, temb=None):
+        return dr.ada_layer_norm(P32, _sd(self), "", x, temb, self.eps)
+
+
+class CogVideoXAttnProcessor2_0:
+    pass
+
+
+class Attention(nn.Module):
+    def __init__(self, query_dim, dim_head, heads, qk_norm, eps, bias, out_bias, processor):
+        super().__init__()
+        assert qk_norm == "layer_norm"
+        inner = dim_head * heads
+        self.heads = heads
+        self.to_q = nn.Linear(query_dim, inner, bias=bias)
+        self.to_k = nn.Linear(query_dim, inner, bias=bias)
+        self.to_v = nn.Linear(query_dim, inner, bias=bias)
+        self.norm_q = nn.LayerNorm(dim_head, eps=eps)
+        self.norm_k = nn.LayerNorm(dim_head, eps=eps)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim, bias=out_bias), nn.Dropout(0.0)])
+        self.eps = eps
+
+    def forward(self, hidden_states, encoder_hidden_states, image_rotary_emb=None):
+        return dr.cogvideox_attention(P32, _sd(self), "", hidden_states, encoder_hidden_states, self.heads,
+                                      image_rotary_emb, self.eps)
+
+
+class _GELU(nn.Module):
+    def __init__(self, d, inner, bias):
+        super().__init__()
+        self.proj = nn.Linear(d, inner, bias=bias)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dropout=0.0, activation_fn="gelu-approximate", final_dropout=True, inner_dim=None, bias=True):
+        super().__init__()
+        assert activation_fn == "gelu-approximate"
+        inner = inner_dim or 4 * dim
+        self.net = nn.ModuleList([_GELU(dim, inner, bias), nn.Dropout(dropout), nn.Linear(inner, dim, bias=bias),
+                                  nn.Dropout(dropout)])
+
+    def forward(self, x):
+        return dr.feed_forward(P32, _sd(self), "", x)
+
+
+class CogVideoXUpsample3D(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, compress_time=False):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding)
+        self.compress_time = compress_time
+
+    def forward(self, x):
+        return dr.upsample3d(P32, _sd(self), "", x, self.compress_time)
+
+
+class CogVideoXDownsample3D(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=2, padding=0, compress_time=False):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding)
+        self.compress_time = compress_time
+
+    def forward(self, x):
+        return dr.downsample3d(P32, _sd(self), "", x, self.compress_time)
+
+
+@dataclass
+class _Out:
+    sample: torch.Tensor = None
+    latent_dist: object = None
+
+    def __getitem__(self, i):
+        return [v for v in (self.sample, self.latent_dist) if v is not None][i]
+
+
+class _Sched:
+    """diffusers-shaped shell around the restated DDIMScheduler."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self):
+        self.s = dr.DDIMScheduler()
+
+    def set_timesteps(self, n, device=None):
+        self.s.set_timesteps(n)
+        self.timesteps = self.s.timesteps
+
+    def scale_model_input(self, x, t):
+        return x
+
+    def step(self, model_output, t, sample, eta=0.0, return_dict=False, generator=None):
+        return (self.s.step(P32, model_output, int(t), sample, eta),)
+
+
+class DiffusionPipeline:
+    def register_modules(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    _execution_device = torch.device("cpu")
+    device = torch.device("cpu")
+
+    @property
+    def dtype(self):
+        return self.transformer.dtype
+
+    def progress_bar(self, total=None):
+        class _PB:
+            def __enter__(s):
+                return s
+
+            def __exit__(s, *a):
+                return False
+
+            def update(s, *a):
+                pass
+
+        return _PB()
+
+    def maybe_free_model_hooks(self):
+        pass
+
+
+class VaeImageProcessor:
+    def __init__(self, vae_scale_factor=8, do_normalize=True, do_binarize=False, do_convert_grayscale=False):
+        self.kw = dict(do_normalize=do_normalize, do_binarize=do_binarize)
+
+    def preprocess(self, image, height=None, width=None):
+        return dr.vae_image_preprocess(image, height, width, **self.kw)
+
+
+def install_scaffolding():
+    ident = lambda f: f  # noqa: E731
+    _mod("diffusers")
+    _mod("diffusers.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=register_to_config)
+    _mod("diffusers.utils", is_torch_version=lambda *a: True, logging=types.SimpleNamespace(get_logger=lambda n: _Logger()),
+         BaseOutput=object, replace_example_docstring=lambda s: ident, WEIGHTS_NAME="diffusion_pytorch_model.bin")
+    _mod("diffusers.utils.torch_utils", maybe_allow_in_graph=ident,
+         randn_tensor=lambda shape, generator=None, device=None, dtype=None: torch.randn(shape, generator=generator, dtype=dtype))
+    _mod("diffusers.utils.accelerate_utils", apply_forward_hook=ident)
+    _mod("diffusers.loaders")
+    _mod("diffusers.loaders.single_file_model", FromOriginalModelMixin=type("FromOriginalModelMixin", (), {}))
+    _mod("diffusers.models", AutoencoderKLCogVideoX=object)
+    _mod("diffusers.models.attention", Attention=Attention, FeedForward=FeedForward)
+    _mod("diffusers.models.attention_processor", AttentionProcessor=object,
+         CogVideoXAttnProcessor2_0=CogVideoXAttnProcessor2_0, FusedCogVideoXAttnProcessor2_0=CogVideoXAttnProcessor2_0)
+    _mod("diffusers.models.embeddings", TimestepEmbedding=TimestepEmbedding, Timesteps=Timesteps,
+         get_3d_sincos_pos_embed=lambda d, hw, t, *a, **k: np.zeros((t, hw[0] * hw[1], d), dtype=np.float32),
+         get_3d_rotary_pos_embed=lambda embed_dim, crops_coords, grid_size, temporal_size, use_real=True:
+         dr.get_3d_rotary_pos_embed(embed_dim, crops_coords, grid_size, temporal_size))
+    _mod("diffusers.models.modeling_outputs", Transformer2DModelOutput=_Out,
+         AutoencoderKLOutput=lambda latent_dist: _Out(latent_dist=latent_dist))
+    _mod("diffusers.models.modeling_utils", ModelMixin=ModelMixin)
+    _mod("diffusers.models.normalization", AdaLayerNorm=AdaLayerNorm, CogVideoXLayerNormZero=CogVideoXLayerNormZero)
+    _mod("diffusers.models.activations", get_activation=lambda n: nn.SiLU())
+    _mod("diffusers.models.downsampling", CogVideoXDownsample3D=CogVideoXDownsample3D)
+    _mod("diffusers.models.upsampling", CogVideoXUpsample3D=CogVideoXUpsample3D)
+    _mod("diffusers.models.autoencoders")
+    _mod("diffusers.models.autoencoders.vae", DecoderOutput=_Out, DiagonalGaussianDistribution=dr.DiagonalGaussian)
+    _mod("diffusers.callbacks", MultiPipelineCallbacks=type("M", (), {}), PipelineCallback=type("PC", (), {}))
+    _mod("diffusers.pipelines")
+    _mod("diffusers.pipelines.pipeline_utils", DiffusionPipeline=DiffusionPipeline)
+    _mod("diffusers.schedulers", CogVideoXDDIMScheduler=type("A", (), {}), CogVideoXDPMScheduler=type("B", (), {}))
+    _mod("diffusers.video_processor", VideoProcessor=lambda vae_scale_factor=8: None)
+    _mod("diffusers.image_processor", VaeImageProcessor=VaeImageProcessor)
+    if "transformers" not in sys.modules:
+        try:
+            import transformers  # noqa: F401
+        except Exception:
+            _mod("transformers", T5EncoderModel=object, T5Tokenizer=object)
+
+
+# --------------------------------------------------------------------------- fixtures
+TINY_TR = dict(num_attention_heads=2, attention_head_dim=64, in_channels=33, out_channels=16, num_layers=2,
+               text_embed_dim=32, time_embed_dim=32, max_text_seq_length=10, sample_width=12, sample_height=8,
+               sample_frames=9, use_rotary_positional_embeddings=True, is_train_cross=True,
+               cross_attn_in_channels=16, cross_attn_interval=2, cross_attn_dim_head=32, cross_attn_num_heads=2)
+TINY_VAE = dict(block_out_channels=(8, 16, 16, 32), norm_num_groups=4, layers_per_block=1)
+
+
+def bf16_round(sd):
+    return {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+
+
+def save(name, tensors, meta):
+    from safetensors.torch import save_file
+    out = {}
+    for k, v in tensors.items():
+        out[k] = v.contiguous()
+    save_file(out, os.path.join(HERE, name), metadata={k: str(v) for k, v in meta.items()})
+    sz = os.path.getsize(os.path.join(HERE, name))
+    print(f"wrote {name}: {len(out)} tensors, {sz / 1e6:.2f} MB")
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit("make_golden.py needs /root/reference (build container only)")
+    install_scaffolding()
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    from models.crosstransformer3d import CrossTransformer3DModel
+    from models.autoencoder_magvit import AutoencoderKLCogVideoX
+    from models import pipeline_trajectorycrafter as ref_pl
+
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1234)
+
+    # ---- transformer forward ------------------------------------------------
+    tr_sd = bf16_round(iw.random_state_dict(iw.transformer_param_shapes(TINY_TR), seed=0))
+    model = CrossTransformer3DModel(**TINY_TR).eval()
+    missing = model.load_state_dict(tr_sd, strict=True)
+    print("transformer load:", missing)
+    B, T, h, w = 2, 3, 8, 12
+    hs = torch.randn(B, T, 16, h, w, generator=g)
+    enc = torch.randn(B, 10, 32, generator=g)
+    inp = torch.randn(B, T, 17, h, w, generator=g)
+    cross = torch.randn(B, 2, 16, h, w, generator=g)
+    ts = torch.tensor([961, 961])
+    from oracle.pipeline import prepare_rotary
+    cos, sin = prepare_rotary(h * 8, w * 8, T, 2, 64)
+    with torch.no_grad():
+        out = model(hs, enc, ts, inpaint_latents=inp, cross_latents=cross, image_rotary_emb=(cos, sin),
+                    return_dict=False)[0]
+        # per-component taps from the reference's own sub-modules
+        emb = model.time_embedding(model.time_proj(ts))
+        pe = model.patch_embed(enc, torch.cat([hs, inp], 2))
+        ref_tok = model.ref_patch_embed(cross)
+        blk_h, blk_e = model.transformer_blocks[0](pe[:, 10:], pe[:, :10], emb, (cos, sin))
+        ca = model.perceiver_cross_attention[0](ref_tok, blk_h)
+    tens = {"w." + k: v.to(torch.bfloat16) for k, v in tr_sd.items()}
+    tens.update(hidden_states=hs, encoder_hidden_states=enc, inpaint_latents=inp, cross_latents=cross,
+                timestep=ts, rope_cos=cos, rope_sin=sin, out_sample=out, tap_patch_embed=pe,
+                tap_ref_tokens=ref_tok, tap_block0_hidden=blk_h, tap_block0_encoder=blk_e, tap_cross0=ca)
+    save("transformer_tiny.safetensors", tens, dict(config=repr(TINY_TR), source="reference CrossTransformer3DModel.forward"))
+
+    # ---- VAE decode / encode --------------------------------------------------
+    vae_sd = bf16_round(iw.random_state_dict(iw.vae_param_shapes(TINY_VAE), seed=1))
+    vae = AutoencoderKLCogVideoX(**TINY_VAE).eval()
+    print("vae load:", vae.load_state_dict(vae_sd, strict=True))
+    z = torch.randn(1, 16, 5, 4, 6, generator=g)
+    video = torch.rand(1, 3, 9, 32, 48, generator=g) * 2 - 1
+    with torch.no_grad():
+        dec = vae.decode(z).sample
+        post = vae.encode(video)[0]
+        dec1 = vae.decode(z[:, :, :1]).sample
+    tens = {"w." + k: v.to(torch.bfloat16) for k, v in vae_sd.items()}
+    tens.update(z=z, decoded=dec, decoded_single_frame=dec1, video=video, enc_mean=post.mean.contiguous(),
+                enc_logvar=post.logvar.contiguous())
+    save("vae_tiny.safetensors", tens, dict(config=repr(TINY_VAE), source="reference AutoencoderKLCogVideoX.decode/encode"))
+
+    # ---- full pipeline (2 steps, CFG 6, 9 frames 32x48) -----------------------
+    pipe = ref_pl.TrajCrafter_Pipeline(tokenizer=None, text_encoder=None, vae=vae, transformer=model, scheduler=_Sched())
+    Fv, H, W = 9, 32, 48
+    vid = torch.rand(1, 3, Fv, H, W, generator=g)
+    mask = (torch.rand(1, 1, Fv, H // 8, W // 8, generator=g) < 0.3).float().repeat_interleave(8, 3).repeat_interleave(8, 4) * 255
+    mask[:, :, 0] = 0
+    ref = vid[:, :, :5].clone()
+    pe_pos = torch.randn(1, 10, 32, generator=g)
+    pe_neg = torch.randn(1, 10, 32, generator=g)
+    lat0 = torch.randn(1, 3, 16, H // 8, W // 8, generator=g)
+    torch.manual_seed(77)                                  # reference latents come from the GLOBAL rng (:886)
+    with torch.no_grad():
+        frames = pipe(prompt=None, negative_prompt=None, height=H, width=W, video=vid, mask_video=mask,
+                      reference=ref, num_frames=Fv, num_inference_steps=2, guidance_scale=6.0,
+                      latents=lat0.clone(), prompt_embeds=pe_pos, negative_prompt_embeds=pe_neg).videos
+        torch.manual_seed(77)
+        lat_out = pipe(prompt=None, negative_prompt=None, height=H, width=W, video=vid, mask_video=mask,
+                       reference=ref, num_frames=Fv, num_inference_steps=2, guidance_scale=6.0,
+                       latents=lat0.clone(), prompt_embeds=pe_pos, negative_prompt_embeds=pe_neg,
+                       output_type="latent", return_dict=True).videos
+    save("pipeline_tiny.safetensors",
+         dict(video=vid, mask_video=mask, reference=ref, prompt_embeds=pe_pos, negative_prompt_embeds=pe_neg,
+              latents0=lat0, frames=frames.float(), latents_out=lat_out.float()),
+         dict(tr_config=repr(TINY_TR), vae_config=repr(TINY_VAE), steps=2, guidance_scale=6.0, global_seed=77,
+              weights="transformer_tiny.safetensors + vae_tiny.safetensors",
+              source="reference TrajCrafter_Pipeline.__call__"))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+"""Oracle vs the committed golden fixtures (generated from the reference's own classes by
+tests/golden/make_golden.py).  CPU only."""
+import ast
+
+import torch
+
+from oracle import pipeline as opl
+from oracle import transformer as otr
+from oracle import vae as ovae
+from oracle import diffusers_restated as dr
+from oracle.prec import Prec
+
+
+def _weights(t):
+    return {k[2:]: v.float() for k, v in t.items() if k.startswith("w.")}
+
+
+def _close(a, b, rtol=2e-4, atol=2e-5):
+    torch.testing.assert_close(a.float(), b.float(), rtol=rtol, atol=atol)
+
+
+def test_transformer_forward_matches_reference(golden):
+    t, meta = golden("transformer_tiny.safetensors")
+    cfg = ast.literal_eval(meta["config"])
+    sd = _weights(t)
+    taps = {}
+    out = otr.transformer_forward(sd, cfg, t["hidden_states"], t["encoder_hidden_states"], t["timestep"],
+                                  t["inpaint_latents"], t["cross_latents"], (t["rope_cos"], t["rope_sin"]),
+                                  prec="fp32", taps=taps)
+    _close(out, t["out_sample"])
+    _close(taps["patch_embed"], t["tap_patch_embed"][:, 10:])
+
+
+def test_transformer_components_match_reference(golden):
+    t, meta = golden("transformer_tiny.safetensors")
+    cfg = dict(otr.DEFAULT_CONFIG)
+    cfg.update(ast.literal_eval(meta["config"]))
+    sd = _weights(t)
+    p = Prec("fp32")
+    D = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    emb = dr.timestep_embedding(p, sd, "time_embedding.", dr.timesteps_proj(t["timestep"], D))
+    pe = t["tap_patch_embed"]
+    h, e = otr.cogvideox_block(p, sd, "transformer_blocks.0.", pe[:, 10:], pe[:, :10], emb,
+                               (t["rope_cos"], t["rope_sin"]), cfg["num_attention_heads"], cfg["norm_eps"])
+    _close(h, t["tap_block0_hidden"])
+    _close(e, t["tap_block0_encoder"])
+    ref_tok = otr.patch_embed_video(p, sd["ref_patch_embed.proj.weight"], sd["ref_patch_embed.proj.bias"],
+                                    t["cross_latents"], 2)
+    _close(ref_tok, t["tap_ref_tokens"])
+    ca = otr.perceiver_cross_attention(p, sd, "perceiver_cross_attention.0.", t["tap_ref_tokens"],
+                                       t["tap_block0_hidden"], cfg["cross_attn_num_heads"], cfg["cross_attn_dim_head"])
+    _close(ca, t["tap_cross0"])
+
+
+def test_vae_decode_encode_match_reference(golden):
+    t, meta = golden("vae_tiny.safetensors")
+    cfg = ast.literal_eval(meta["config"])
+    sd = _weights(t)
+    _close(ovae.vae_decode(sd, cfg, t["z"]), t["decoded"])
+    _close(ovae.vae_decode(sd, cfg, t["z"][:, :, :1]), t["decoded_single_frame"])
+    post = ovae.vae_encode(sd, cfg, t["video"])
+    _close(post.mean, t["enc_mean"])
+    _close(post.logvar, t["enc_logvar"])
+
+
+def test_pipeline_matches_reference(golden):
+    tp, meta = golden("pipeline_tiny.safetensors")
+    tt, mt = golden("transformer_tiny.safetensors")
+    tv, mv = golden("vae_tiny.safetensors")
+    tr_cfg, vae_cfg = ast.literal_eval(mt["config"]), ast.literal_eval(mv["config"])
+    torch.manual_seed(int(meta["global_seed"]))      # the reference samples ref latents from the global RNG
+    kw = dict(prompt_embeds=tp["prompt_embeds"], negative_prompt_embeds=tp["negative_prompt_embeds"],
+              video=tp["video"], mask_video=tp["mask_video"], reference=tp["reference"], height=32, width=48,
+              latents=tp["latents0"], num_inference_steps=2, guidance_scale=6.0, num_frames=9)
+    lat = opl.pipeline_call(_weights(tt), tr_cfg, _weights(tv), vae_cfg, output_type="latent", **kw)
+    _close(lat, tp["latents_out"], rtol=1e-3, atol=1e-4)
+    torch.manual_seed(int(meta["global_seed"]))
+    frames = opl.pipeline_call(_weights(tt), tr_cfg, _weights(tv), vae_cfg, **kw)
+    _close(frames, tp["frames"], rtol=1e-3, atol=1e-4)
+    assert frames.shape == (1, 3, 9, 32, 48) and float(frames.min()) >= 0 and float(frames.max()) <= 1

@@ -1,0 +1,163 @@
+"""Analytic known-answer tests for the restated `diffusers` arithmetic (parity unpinned by the
+reference: it holds no tests or vectors for these; see oracle/diffusers_restated.py)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import diffusers_restated as dr
+from oracle.pipeline import get_resize_crop_region_for_grid, prepare_rotary, resize_mask
+from oracle.prec import Prec
+
+P = Prec("fp32")
+
+
+def test_timesteps_flip_sin_to_cos():
+    e = dr.timesteps_proj(torch.tensor([0, 7]), 8, True, 0)
+    assert e.shape == (2, 8)
+    torch.testing.assert_close(e[0], torch.tensor([1., 1, 1, 1, 0, 0, 0, 0]))
+    f = torch.exp(-math.log(10000) * torch.arange(4) / 4)
+    torch.testing.assert_close(e[1, :4], torch.cos(7 * f))
+    torch.testing.assert_close(e[1, 4:], torch.sin(7 * f))
+
+
+def test_layer_norm_zero_chunk_order_and_modulation():
+    D, te = 4, 3
+    sd = {"linear.weight": torch.zeros(6 * D, te), "linear.bias": torch.arange(6 * D).float(),
+          "norm.weight": torch.ones(D), "norm.bias": torch.zeros(D)}
+    x = torch.tensor([[[1., 2, 3, 4]]])
+    enc = torch.tensor([[[4., 3, 2, 1]]])
+    h, e, g, eg = dr.layer_norm_zero(P, sd, "", x, enc, torch.zeros(1, te), 1e-5)
+    n = F.layer_norm(x, (D,), eps=1e-5)
+    shift, scale, gate = sd["linear.bias"][0:4], sd["linear.bias"][4:8], sd["linear.bias"][8:12]
+    torch.testing.assert_close(h, n * (1 + scale) + shift)
+    torch.testing.assert_close(g[0, 0], gate)
+    ne = F.layer_norm(enc, (D,), eps=1e-5)
+    torch.testing.assert_close(e, ne * (1 + sd["linear.bias"][16:20]) + sd["linear.bias"][12:16])
+    torch.testing.assert_close(eg[0, 0], sd["linear.bias"][20:24])
+
+
+def test_ada_layer_norm_shift_first():
+    D, te = 4, 2
+    sd = {"linear.weight": torch.zeros(2 * D, te), "linear.bias": torch.arange(2 * D).float(),
+          "norm.weight": torch.ones(D), "norm.bias": torch.zeros(D)}
+    x = torch.tensor([[[1., 2, 3, 5]]])
+    y = dr.ada_layer_norm(P, sd, "", x, torch.zeros(1, te), 1e-5)
+    n = F.layer_norm(x, (D,), eps=1e-5)
+    torch.testing.assert_close(y, n * (1 + torch.arange(4, 8).float()) + torch.arange(0, 4).float())
+
+
+def test_rope_tables_and_rotation():
+    cos, sin = dr.get_3d_rotary_pos_embed(64, ((0, 0), (30, 45)), (30, 45), 13)
+    assert cos.shape == (13 * 30 * 45, 64) and cos.dtype == torch.float32
+    # token (t=2,h=3,w=5): dims 0:16 temporal, 16:40 height, 40:64 width, each freq repeated twice
+    idx = (2 * 30 + 3) * 45 + 5
+    ft = 1.0 / (10000 ** (torch.arange(0, 16, 2).float() / 16))
+    fh = 1.0 / (10000 ** (torch.arange(0, 24, 2).float() / 24))
+    exp = torch.cat([(2 * ft).repeat_interleave(2), (3 * fh).repeat_interleave(2), (5 * fh).repeat_interleave(2)])
+    torch.testing.assert_close(cos[idx], exp.cos())
+    torch.testing.assert_close(sin[idx], exp.sin())
+    # rotation of adjacent pairs: (a,b) -> (a cos - b sin, b cos + a sin)
+    x = torch.randn(1, 1, 1, 64)
+    y = dr.apply_rotary_emb(x, cos[idx:idx + 1], sin[idx:idx + 1])
+    a, b = x[0, 0, 0, 0::2], x[0, 0, 0, 1::2]
+    c, s = exp.cos()[0::2], exp.sin()[0::2]
+    torch.testing.assert_close(y[0, 0, 0, 0::2], a * c - b * s)
+    torch.testing.assert_close(y[0, 0, 0, 1::2], b * c + a * s)
+    # norm preserved
+    torch.testing.assert_close(y.norm(), x.norm())
+
+
+def test_rope_crop_region_384x672_is_fractional():
+    assert get_resize_crop_region_for_grid((30, 45), 45, 30) == ((0, 0), (30, 45))
+    assert get_resize_crop_region_for_grid((24, 42), 45, 30) == ((2, 0), (28, 45))
+    cos, _ = prepare_rotary(384, 672, 13, 2, 64)
+    assert cos.shape == (13 * 24 * 42, 64)
+
+
+def test_ddim_zero_terminal_snr_and_trailing_timesteps():
+    s = dr.DDIMScheduler()
+    assert abs(float(s.alphas_cumprod[-1])) < 1e-10          # zero terminal SNR
+    assert abs(float(s.alphas_cumprod[0]) - (1 - 0.00085)) < 1e-6
+    s.set_timesteps(50)
+    assert s.timesteps[0] == 999 and s.timesteps[-1] == 19 and len(s.timesteps) == 50
+    assert torch.all(s.timesteps[:-1] - s.timesteps[1:] == 20)
+    # v-prediction at t=999 (abar=0): x0 = -v, eps = sample
+    x = torch.randn(1, 2, 3)
+    v = torch.randn(1, 2, 3)
+    a_prev = s.alphas_cumprod[979]
+    out = s.step(P, v, 999, x)
+    torch.testing.assert_close(out, a_prev.sqrt() * (-v) + (1 - a_prev).sqrt() * x, rtol=1e-5, atol=1e-6)
+    # last step lands on x0 (final alpha = 1)
+    a = s.alphas_cumprod[19]
+    out = s.step(P, v, 19, x)
+    torch.testing.assert_close(out, a.sqrt() * x - (1 - a).sqrt() * v, rtol=1e-5, atol=1e-6)
+
+
+def test_ddim_bf16_promotion_quirk():
+    s = dr.DDIMScheduler()
+    s.set_timesteps(50)
+    pb = Prec("bf16")
+    x = torch.randn(64).to(torch.bfloat16)
+    v = torch.randn(64)
+    a, ap = s.coeffs(499)
+    out = s.step(pb, v, 499, x)
+    sa, sb = a.sqrt(), (1 - a).sqrt()
+    x0 = (sa * x.float()).bfloat16().float() - sb * v
+    eps = sa * v + (sb * x.float()).bfloat16().float()
+    torch.testing.assert_close(out, ap.sqrt() * x0 + (1 - ap).sqrt() * eps)
+
+
+def test_upsample3d_frame_rules():
+    x = torch.arange(3.)[None, None, :, None, None].expand(1, 1, 3, 2, 2)
+    y = dr.upsample3d_nearest(x, True)                 # odd T: frame0 spatial only, rest x2 in time
+    assert y.shape == (1, 1, 5, 4, 4)
+    assert y[0, 0, :, 0, 0].tolist() == [0, 1, 1, 2, 2]
+    y = dr.upsample3d_nearest(x[:, :, :2], True)
+    assert y.shape == (1, 1, 4, 4, 4) and y[0, 0, :, 0, 0].tolist() == [0, 0, 1, 1]
+    y = dr.upsample3d_nearest(x, False)
+    assert y.shape == (1, 1, 3, 4, 4)
+
+
+def test_sdpa_matches_torch():
+    q, k, v = torch.randn(3, 2, 2, 17, 8).unbind(0)
+    torch.testing.assert_close(dr.sdpa(P, q, k, v, 8 ** -0.5), F.scaled_dot_product_attention(q, k, v),
+                               rtol=1e-5, atol=1e-6)
+
+
+def test_feed_forward_gelu_tanh():
+    sd = {"net.0.proj.weight": torch.eye(3), "net.0.proj.bias": torch.zeros(3),
+          "net.2.weight": torch.eye(3), "net.2.bias": torch.zeros(3)}
+    x = torch.tensor([[-1.0, 0.0, 2.0]])
+    g = 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))
+    torch.testing.assert_close(dr.feed_forward(P, sd, "", x), g)
+
+
+def test_resize_mask_first_frame_separate():
+    m = torch.zeros(1, 1, 9, 16, 16)
+    m[:, :, 0] = 1
+    lat = torch.zeros(1, 16, 3, 2, 2)
+    r = resize_mask(m, lat)
+    assert r.shape == (1, 1, 3, 2, 2)
+    assert torch.all(r[:, :, 0] == 1) and torch.all(r[:, :, 1:] == 0)
+
+
+def test_image_preprocess_and_mask_binarise():
+    x = torch.tensor([0.0, 0.25, 1.0]).view(1, 1, 1, 3)
+    torch.testing.assert_close(dr.vae_image_preprocess(x, 1, 3), torch.tensor([-1.0, -0.5, 1.0]).view(1, 1, 1, 3))
+    m = torch.tensor([0.0, 0.4, 255.0]).view(1, 1, 1, 3)
+    assert dr.vae_image_preprocess(m, 1, 3, do_normalize=False, do_binarize=True).flatten().tolist() == [0, 0, 1]
+
+
+def test_precision_modes_are_ordered():
+    """bf16 contract is at least as close to fp32 as the reference's per-op bf16 rounding."""
+    torch.manual_seed(0)
+    D, te = 64, 16
+    sd = {"linear.weight": torch.randn(6 * D, te) * 0.1, "linear.bias": torch.randn(6 * D) * 0.1,
+          "norm.weight": torch.ones(D), "norm.bias": torch.zeros(D)}
+    x, e, t = torch.randn(2, 50, D), torch.randn(2, 5, D), torch.randn(2, te)
+    ref = dr.layer_norm_zero(Prec("fp32"), sd, "", x, e, t, 1e-5)[0]
+    c = dr.layer_norm_zero(Prec("bf16"), sd, "", x.bfloat16().float(), e.bfloat16().float(), t.bfloat16().float(), 1e-5)[0]
+    r = dr.layer_norm_zero(Prec("bf16_ref"), sd, "", x.bfloat16().float(), e.bfloat16().float(), t.bfloat16().float(), 1e-5)[0]
+    assert (c - ref).abs().mean() <= (r - ref).abs().mean() * 1.05
