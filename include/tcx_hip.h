@@ -1,0 +1,182 @@
+/* libtcx_hip.so — C ABI of the MI355X (gfx950) kernels behind the TrajectoryCrafter denoising path.
+ *
+ * The reference (alekseizhuravlev/TrajectoryCrafter) has no native code and no FFI: every kernel
+ * below replaces an *implicit* torch/cuDNN/flash-SDPA dispatch inside the reference's Python hot
+ * path.  Each entry point cites the reference statement(s) it replaces (file:line relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions (face B2)
+ *   - plain C types only; every pointer is a DEVICE pointer owned by the caller
+ *   - bf16 tensors are raw uint16 storage; "row" tensors are row-major with the stated strides
+ *     (strides are in ELEMENTS)
+ *   - asynchronous: kernels are enqueued on `stream` (a hipStream_t passed as void*); the library
+ *     never allocates, frees or synchronises
+ *   - return value: 0 on success, a negative TCX_E_* code on argument errors, or a positive
+ *     hipError_t from the launch; tcx_last_error_string() gives a thread-local message
+ *   - stateless and re-entrant; safe from several host threads on different streams / devices
+ */
+#ifndef TCX_HIP_H
+#define TCX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCX_OK 0
+#define TCX_E_SHAPE (-1)      /* unsupported / inconsistent shape            */
+#define TCX_E_DTYPE (-2)      /* unsupported dtype enum                      */
+#define TCX_E_ALIGN (-3)      /* pointer or stride not aligned as required   */
+#define TCX_E_NULL (-4)       /* required pointer is null                    */
+
+#define TCX_BF16 0
+#define TCX_F32 1
+
+/* ---- library info ---------------------------------------------------------------------- */
+int tcx_version(void);                       /* ABI version, currently 1 */
+const char* tcx_last_error_string(void);     /* thread-local description of the last failure */
+/* Fills {CU count, LDS bytes per CU, wavefront size, gcnArch major*100+minor*10+step}. */
+int tcx_device_info(int device, int32_t out[4]);
+
+/* ---- K1 / K3: fused attention forward -------------------------------------------------------
+ * O = softmax(scale * Q K^T) V, no mask, online softmax in fp32, P rounded to bf16 before PV.
+ * Replaces: F.scaled_dot_product_attention inside diffusers CogVideoXAttnProcessor2_0, called
+ *   at models/crosstransformer3d.py:239-243 (joint text+video self-attention, D=64, scale 1/8)
+ *   and the (q*s)@(k*s)^T -> softmax -> @v chain of PerceiverCrossAttention.forward,
+ *   models/crosstransformer3d.py:391-395 (D=128; q,k pre-scaled -> scale = 1).
+ * q/k/v/o: bf16 [B, S, H, D] views: element (b,s,h,d) at b*stride_b + s*stride_s + h*stride_h + d.
+ * D in {64, 128}; all strides multiples of 8 elements and pointers 16-byte aligned.
+ * out_dtype: TCX_BF16 (product path) or TCX_F32 (test-only higher precision output). */
+int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o,
+                 int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t D,
+                 int64_t q_stride_b, int64_t q_stride_s, int64_t q_stride_h,
+                 int64_t k_stride_b, int64_t k_stride_s, int64_t k_stride_h,
+                 int64_t v_stride_b, int64_t v_stride_s, int64_t v_stride_h,
+                 int64_t o_stride_b, int64_t o_stride_s, int64_t o_stride_h,
+                 float scale, int32_t out_dtype, void* stream);
+
+/* ---- K2: per-head LayerNorm(D=64) on q and k + 3-D RoPE on the video tokens, in place ---------
+ * Replaces: attn.norm_q / attn.norm_k (LayerNorm(64, eps 1e-6, affine)) and apply_rotary_emb on
+ *   query[:, :, text_len:] / key[:, :, text_len:] in diffusers CogVideoXAttnProcessor2_0 (module
+ *   built at models/crosstransformer3d.py:199-208; tables from
+ *   models/pipeline_trajectorycrafter.py:616-649).
+ * q, k: bf16 [B, S, H, 64] views (same stride convention as tcx_attn_fwd).  gamma/beta: bf16 [64].
+ * cos/sin: fp32 [S - text_len, 64] (may be null -> no rotation).  fp32 math, one rounding. */
+int tcx_qk_layernorm_rope(void* q, void* k,
+                          int32_t B, int32_t S, int32_t H, int32_t D,
+                          int64_t stride_b, int64_t stride_s, int64_t stride_h,
+                          const void* gamma_q, const void* beta_q, const void* gamma_k, const void* beta_k,
+                          const float* cos, const float* sin, int32_t text_len, float eps, void* stream);
+
+/* ---- K4: LayerNorm (+ optional AdaLN modulate) over rows of C channels ------------------------
+ * y = LN(x) * gamma + beta, then optionally y = y * (1 + scale[b]) + shift[b], with separate
+ * (shift, scale) for the first `text_len` rows of each batch item (text) and the rest (video).
+ * Replaces: diffusers CogVideoXLayerNormZero.forward (norm1/norm2, models/crosstransformer3d.py:
+ *   195-197,211-213,234-236,251-253), nn.LayerNorm norm_final (:553,849), diffusers AdaLayerNorm
+ *   norm_out (:556-562,856) and PerceiverCrossAttention.norm1/norm2 (:314-315,379-380).
+ * x, y: bf16 [B, rows_per_batch, C] with batch strides (elements); rows contiguous (stride C).
+ * gamma/beta: bf16 [C] or null.  shift_v/scale_v/shift_t/scale_t: bf16 [B, C] with stride
+ * mod_stride_b between batch items, or null (no modulation).  C % 8 == 0, C <= 8192. */
+int tcx_layernorm_modulate(const void* x, void* y, int32_t B, int32_t rows_per_batch, int32_t C,
+                           int64_t x_stride_b, int64_t y_stride_b,
+                           const void* gamma, const void* beta,
+                           const void* shift_v, const void* scale_v,
+                           const void* shift_t, const void* scale_t, int64_t mod_stride_b,
+                           int32_t text_len, float eps, void* stream);
+
+/* ---- K5: gated residual, in place ---------------------------------------------------------------
+ * x[b, r, :] += gate[b, :] * y[b, r, :]   (gate_t for rows < text_len, gate_v otherwise;
+ * null gates mean gate = 1: the plain cross-attention residual).
+ * Replaces: models/crosstransformer3d.py:245-248, 261-264 (gated residuals) and :833-837. */
+int tcx_gated_residual(void* x, const void* y, int32_t B, int32_t rows_per_batch, int32_t C,
+                       int64_t x_stride_b, int64_t y_stride_b,
+                       const void* gate_v, const void* gate_t, int64_t gate_stride_b,
+                       int32_t text_len, void* stream);
+
+/* ---- K6 epilogue: y = gelu_tanh(x + bias) over [rows, C] bf16 (bias bf16 [C] or null) ---------
+ * Replaces: the GELU(approximate="tanh") of diffusers FeedForward net.0 (module built at
+ *   models/crosstransformer3d.py:215-222, run :259). */
+int tcx_bias_gelu_tanh(const void* x, const void* bias, void* y, int64_t rows, int32_t C, void* stream);
+
+/* ---- elementwise helpers -------------------------------------------------------------------- */
+/* y = bf16(x * s): the q*scale / k*scale of PerceiverCrossAttention (crosstransformer3d.py:391-392). */
+int tcx_scale_bf16(const void* x, void* y, int64_t n, float s, void* stream);
+/* y = silu(x), bf16 -> bf16: the SiLU in front of every AdaLN linear (diffusers LayerNormZero/AdaLayerNorm). */
+int tcx_silu_bf16(const void* x, void* y, int64_t n, void* stream);
+
+/* ---- K8: patchify / unpatchify -------------------------------------------------------------------
+ * patchify: gathers [B,F,C,H,W] (optionally the channel-concat of two tensors a:[.,Ca,.,.] and
+ * b:[.,Cb,.,.]) into the im2col matrix [B*F*(H/p)*(W/p), (Ca+Cb)*p*p] (column order c,py,px =
+ * Conv2d weight.flatten(1)) so the patch embedding is one GEMM.
+ * Replaces: torch.concat + nn.Conv2d(k=p, stride=p) + flatten/transpose in
+ *   CogVideoXPatchEmbed.forward / RefPatchEmbed.forward (models/crosstransformer3d.py:736, 78-87,
+ *   120-135).
+ * unpatchify: [B, F*(H/p)*(W/p), Cout*p*p] -> [B,F,Cout,H,W] (models/crosstransformer3d.py:863-867). */
+int tcx_patchify(const void* a, const void* b, void* out, int32_t B, int32_t F, int32_t Ca, int32_t Cb,
+                 int32_t H, int32_t W, int32_t p, void* stream);
+int tcx_unpatchify(const void* x, void* out, int32_t B, int32_t F, int32_t C, int32_t H, int32_t W,
+                   int32_t p, int32_t out_dtype, void* stream);
+
+/* ---- K10: classifier-free guidance + DDIM step (v-prediction, eta = 0), fused -----------------
+ * noise = u + g*(c - u) in fp32; x0 = bf16r(sa*x) - sb*noise; eps = sa*noise + bf16r(sb*x);
+ * x_prev = bf16r(sqrt(a_prev)*x0 + sqrt(1-a_prev)*eps).  u/c: the two halves of the transformer
+ * output (dtype pred_dtype, TCX_BF16 or TCX_F32), x: bf16 latents, out: bf16 (may alias x).
+ * If `c` is null no guidance is applied (noise = u).
+ * Replaces: models/pipeline_trajectorycrafter.py:1117,1157-1167,1178 with diffusers
+ *   DDIMScheduler.step. */
+int tcx_cfg_ddim_step(const void* u, const void* c, const void* x, void* out, int64_t n,
+                      float guidance, float alpha_t, float alpha_prev, int32_t pred_dtype, void* stream);
+
+/* ---- K11 / K12 / 1x1x1 convs: bf16 implicit-GEMM convolution, channels-last -------------------
+ * y[n, t, oy, ox, co] = bias[co] + sum_{dt,dy,dx,ci} X(t + dt, (oy + dy - ph) , (ox + dx - pw), ci)
+ *                                                    * w[co, dt, dy, dx, ci]   (+ res[n,t,oy,ox,co])
+ * where X is the logical input: rows t < kT-1 come from `cache` (the previous chunk's last kT-1
+ * input frames, or the first frame replicated when cache is null), the rest from `x`; spatial
+ * zero padding; when `ups` = 1 the logical input is the nearest-neighbour x2 spatial upsample of
+ * `x` (never materialised); `t_map` (int32 [T_out], device, or null = identity) maps an output
+ * frame to the source frame of `x` (the temporal part of CogVideoXUpsample3D).
+ * Layouts: x [N, T_in, H_in, W_in, Cin] bf16; w [Cout, kT, kH, kW, Cin] bf16 (pre-permuted by the
+ * host from the reference's [Cout, Cin, kT, kH, kW]); y [N, T_out, H, W, Cout] bf16.
+ * Replaces: CogVideoXCausalConv3d.forward + CogVideoXSafeConv3d (models/autoencoder_magvit.py:
+ *   41-73,136-163), the interpolate + Conv2d of diffusers CogVideoXUpsample3D (built :620-630),
+ *   the 1x1x1 conv_shortcut (:312-318,351-352) and the residual add (:354).
+ * The cache for the next chunk (last kT-1 logical input frames, :157) is a plain slice of
+ * concat(cache, x) that the host keeps; `res` (or null) is added in fp32 before the rounding. */
+int tcx_conv3d_cl(const void* x, const void* cache, const void* w, const void* bias, const void* res,
+                  void* y,
+                  int32_t N, int32_t T_in, int32_t H_in, int32_t W_in, int32_t Cin, int32_t Cout,
+                  int32_t kT, int32_t kH, int32_t kW, int32_t T_out, int32_t ups, const int32_t* t_map,
+                  void* stream);
+
+/* ---- K13: GroupNorm statistics + fused GroupNorm * SpatialNorm modulate + SiLU ----------------
+ * stats: per (n, group) mean / rstd over (T, H, W, C/G) of channels-last x [N, spatial, C] bf16.
+ *   Two launches: per-channel shifted partial sums of `nsplit` row slabs into
+ *   partial (fp32 [N, nsplit, 2, C]), then an fp64 combine -> stats fp32 [N, G, 2] = (mean, rstd).
+ * apply: y = silu( GN(x) * Y[src] + Bt[src] ) when ytab != null, else y = silu(GN(x)) (silu optional).
+ *   Y = conv_y(zq), Bt = conv_b(zq) are the SpatialNorm 1x1x1 convs evaluated at zq's own LOW
+ *   resolution (channels-last [N, Tz, Hz, Wz, C] bf16, produced with tcx_conv3d_cl): a nearest resize
+ *   commutes with a pointwise conv, so the resized zq is never materialised.  z_t_map int32 [T]
+ *   (device) gives the zq frame of every frame of x (the first-frame/rest split of
+ *   autoencoder_magvit.py:200-208); the spatial nearest index is floor(i * Hz / H).
+ * Replaces: CogVideoXSpatialNorm3D.forward (models/autoencoder_magvit.py:199-212) + the SiLU at
+ *   :333,347,951 and nn.GroupNorm + SiLU on the encoder side (:265-270,331-333,345-347,795-796). */
+int tcx_groupnorm_stats(const void* x, float* stats, float* partial, int32_t N, int64_t spatial, int32_t C,
+                        int32_t G, float eps, int32_t nsplit, void* stream);
+int tcx_groupnorm_spatialnorm_silu(const void* x, void* y, const float* stats,
+                                   const void* gn_w, const void* gn_b, const void* ytab, const void* btab,
+                                   int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t G,
+                                   int32_t Tz, int32_t Hz, int32_t Wz, const int32_t* z_t_map,
+                                   int32_t apply_silu, void* stream);
+
+/* ---- K14: layout + final clamp ---------------------------------------------------------------------
+ * ncthw <-> channels-last transposes for the VAE boundary and frames = clamp(x/2 + .5, 0, 1) as fp32
+ * [N, C, T, H, W] (models/pipeline_trajectorycrafter.py:515-517). */
+int tcx_ncthw_to_cl(const void* x, void* y, int32_t N, int32_t C, int64_t spatial, float mul, void* stream);
+int tcx_cl_to_ncthw_frames(const void* x, float* y, int32_t N, int32_t C, int64_t spatial, int64_t out_spatial_stride,
+                           int64_t out_offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCX_HIP_H */

@@ -25,8 +25,11 @@ DEFAULT_CONFIG = dict(
 )
 
 
-def causal_conv3d(p: Prec, sd: dict, prefix: str, x: torch.Tensor, cache: dict) -> torch.Tensor:
-    """reference :136-163.  `prefix` names the CogVideoXCausalConv3d module; weights at prefix+'conv.'."""
+def causal_conv3d(p: Prec, sd: dict, prefix: str, x: torch.Tensor, cache: dict,
+                  res: torch.Tensor | None = None) -> torch.Tensor:
+    """reference :136-163.  `prefix` names the CogVideoXCausalConv3d module; weights at prefix+'conv.'.
+    `res` is the resnet shortcut (:354): the HIP path adds it in the conv epilogue before the single
+    rounding; the reference rounds the conv output first (per-op point)."""
     w, b = sd[prefix + "conv.weight"], sd[prefix + "conv.bias"]
     kt, kh, kw = w.shape[2:]
     if kt > 1:
@@ -35,7 +38,10 @@ def causal_conv3d(p: Prec, sd: dict, prefix: str, x: torch.Tensor, cache: dict) 
         x = torch.cat(ctx + [x], dim=2)
         cache[prefix] = x[:, :, -(kt - 1):].clone()          # saved before spatial padding (:157)
     x = F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2), mode="constant", value=0)
-    return p.R(F.conv3d(x.float(), p.param(w), p.param(b)))
+    y = F.conv3d(x.float(), p.param(w), p.param(b))
+    if res is not None:
+        y = p.r(y) + res
+    return p.R(y)
 
 
 def spatial_norm3d(p: Prec, sd: dict, prefix: str, f, zq, groups: int, cache: dict, silu: bool = True):
@@ -74,11 +80,10 @@ def resnet_block3d(p: Prec, sd: dict, prefix: str, x, zq, groups: int, eps: floa
         h = spatial_norm3d(p, sd, prefix + "norm2.", h, zq, groups, cache)
     else:
         h = group_norm_silu(p, sd, prefix + "norm2.", h, groups, eps)
-    h = causal_conv3d(p, sd, prefix + "conv2.", h, cache)
     if prefix + "conv_shortcut.weight" in sd:                  # CogVideoXSafeConv3d 1x1x1 (:312-318)
-        x = p.r(F.conv3d(x.float(), p.param(sd[prefix + "conv_shortcut.weight"]),
+        x = p.R(F.conv3d(x.float(), p.param(sd[prefix + "conv_shortcut.weight"]),
                          p.param(sd[prefix + "conv_shortcut.bias"])))
-    return p.R(h + x)
+    return causal_conv3d(p, sd, prefix + "conv2.", h, cache, res=x)
 
 
 def decoder_forward(p: Prec, sd: dict, cfg: dict, z: torch.Tensor, cache: dict) -> torch.Tensor:

@@ -1,0 +1,218 @@
+// bf16 implicit-GEMM convolution, channels-last, for the MAGViT/CogVideoX VAE (K11, K12, 1x1x1 convs).
+//
+// GEMM view:  Y^T[co, m] = sum_k W[co, k] * X[m, k],   m = (n, t, oy, ox) output position,
+//             k = (dt, dy, dx, ci) with ci fastest (weights pre-permuted to [Cout, kT, kH, kW, Cin]).
+// The X operand is gathered on the fly: causal temporal context from `cache` (or the first frame
+// replicated), spatial zero padding, optional nearest x2 upsample (ups) and temporal frame map
+// (t_map) folded into the gather index, so neither the padded, the upsampled nor the im2col tensor
+// is ever materialised in HBM.
+//
+// Tiling: 256 threads = 4 waves (2 x 2), block tile 128 (co) x 128 (m) x 32 (k); each wave owns
+// 64 x 64 = 2 x 2 MFMA 32x32x16 tiles.  W is the MFMA A operand and X the B operand, so a lane owns
+// ONE output position and 4 consecutive channels per accumulator quad -> 8-byte channels-last
+// stores.  Both tiles are staged global -> registers -> LDS (issue-early / write-late, double
+// buffered, one barrier per k-tile) in 64-byte rows with an XOR swizzle that makes the
+// ds_read_b128 fragment reads bank-conflict free.
+#include "tcx_common.h"
+
+namespace {
+
+struct ConvParams {
+    const uint16_t *x, *cache, *w, *bias, *res;
+    uint16_t* y;
+    const int32_t* t_map;
+    int32_t N, T_in, H_in, W_in, Cin, Cout, kT, kH, kW, T_out, H, W, ups;
+    int32_t Ktot;       // kT*kH*kW*Cin
+    int64_t M;          // N*T_out*H*W
+    uint32_t ntn, nwg;  // N tiles (co), total workgroups
+};
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int TILE_BYTES = 128 * BK * 2;  // 8 KiB per operand tile
+
+// 64-byte rows, 4 rows per 256-B bank row: XOR the 16-B chunk index with bits 2..3 of the row
+__device__ __forceinline__ int tile_off(int row, int ch) { return row * 64 + ((ch ^ ((row >> 2) & 3)) << 4); }
+
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wn = wave >> 1, wm = wave & 1;     // wave tile: co block wn, position block wm
+
+    const uint32_t id = xcd_remap(blockIdx.x, p.nwg);
+    const uint32_t mt = id / p.ntn, nt = id - mt * p.ntn;
+    const int64_t m0 = (int64_t)mt * BM;
+    const int co0 = nt * BN;
+
+    // ---- staging assignment: each thread owns chunk (tid & 3) of rows (tid >> 2) and (tid >> 2) + 64 ----
+    const int ch = tid & 3;
+    const int HW = p.H * p.W;
+    int xn[2], xt[2], xoy[2], xox[2];
+    bool xvalid[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t m = m0 + (tid >> 2) + 64 * i;
+        xvalid[i] = m < p.M;
+        const int64_t mm = xvalid[i] ? m : 0;
+        const int64_t fr = mm / HW;
+        const int rem = (int)(mm - fr * HW);
+        xoy[i] = rem / p.W;
+        xox[i] = rem - xoy[i] * p.W;
+        xn[i] = (int)(fr / p.T_out);
+        xt[i] = (int)(fr - (int64_t)xn[i] * p.T_out);
+    }
+    const int ph = p.kH >> 1, pw = p.kW >> 1;
+    const int64_t frame_elems = (int64_t)p.H_in * p.W_in * p.Cin;
+
+    u32x4 wreg[2], xreg[2];
+    // k position of this thread's chunk, advanced by BK per k-tile: k = tap * Cin + ci
+    int kk = 8 * ch, tap = 0, ci = 8 * ch;
+    while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+
+    auto stage_load = [&]() {
+        const bool kvalid = kk < p.Ktot;
+        // weights: row co, contiguous k
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int co = co0 + (tid >> 2) + 64 * i;
+            if (kvalid && co < p.Cout) wreg[i] = *reinterpret_cast<const u32x4*>(p.w + (int64_t)co * p.Ktot + kk);
+            else wreg[i] = u32x4{0, 0, 0, 0};
+        }
+        const int dx = tap % p.kW, t2 = tap / p.kW;
+        const int dy = t2 % p.kH, dt = t2 / p.kH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            xreg[i] = u32x4{0, 0, 0, 0};
+            if (!kvalid || !xvalid[i]) continue;
+            const int iy = xoy[i] + dy - ph, ix = xox[i] + dx - pw;
+            if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) continue;
+            const int li = xt[i] + dt;                       // logical input frame (cache frames first)
+            const uint16_t* fb;
+            if (li < p.kT - 1) {
+                if (p.cache) fb = p.cache + ((int64_t)xn[i] * (p.kT - 1) + li) * frame_elems;
+                else fb = p.x + ((int64_t)xn[i] * p.T_in + (p.t_map ? p.t_map[0] : 0)) * frame_elems;
+            } else {
+                const int ts = li - (p.kT - 1);
+                fb = p.x + ((int64_t)xn[i] * p.T_in + (p.t_map ? p.t_map[ts] : ts)) * frame_elems;
+            }
+            xreg[i] = *reinterpret_cast<const u32x4*>(fb + ((int64_t)(iy >> p.ups) * p.W_in + (ix >> p.ups)) * p.Cin + ci);
+        }
+        kk += BK;
+        ci += BK;
+        while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+    };
+    auto stage_write = [&](int buf) {
+        char* wb = smem + buf * 2 * TILE_BYTES;
+        char* xb = wb + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (tid >> 2) + 64 * i;
+            *reinterpret_cast<u32x4*>(wb + tile_off(row, ch)) = wreg[i];
+            *reinterpret_cast<u32x4*>(xb + tile_off(row, ch)) = xreg[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    const int nk = (p.Ktot + BK - 1) / BK;
+    stage_load();
+    stage_write(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const char* wb = smem + buf * 2 * TILE_BYTES;
+        const char* xb = wb + TILE_BYTES;
+        const bool more = kt + 1 < nk;
+        if (more) stage_load();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const bf16x8*>(wb + tile_off(64 * wn + 32 * a + r, 2 * ks + h));
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(xb + tile_off(64 * wm + 32 * b + r, 2 * ks + h));
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) stage_write(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns position m = m0 + 64 wm + 32 b + r and channels co0 + 64 wn + 32 a + 8 i + 4 h + (0..3) ----
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int64_t m = m0 + 64 * wm + 32 * b + r;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + 64 * wn + 32 * a + 8 * i + 4 * h;
+                if (co >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * i + e];
+                if (co + 3 < p.Cout && (p.Cout & 3) == 0) {
+                    if (p.bias) {
+                        const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + co);
+                        v[0] += bf16lo(bb[0]); v[1] += bf16hi(bb[0]); v[2] += bf16lo(bb[1]); v[3] += bf16hi(bb[1]);
+                    }
+                    if (p.res) {
+                        const u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + m * p.Cout + co);
+                        v[0] += bf16lo(rr[0]); v[1] += bf16hi(rr[0]); v[2] += bf16lo(rr[1]); v[3] += bf16hi(rr[1]);
+                    }
+                    u32x2 o;
+                    o[0] = pack_bf16(v[0], v[1]);
+                    o[1] = pack_bf16(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(p.y + m * p.Cout + co) = o;
+                } else {
+                    for (int e = 0; e < 4 && co + e < p.Cout; ++e) {
+                        float t = v[e];
+                        if (p.bias) t += bf16_bits_to_f32(p.bias[co + e]);
+                        if (p.res) t += bf16_bits_to_f32(p.res[m * p.Cout + co + e]);
+                        p.y[m * p.Cout + co + e] = (uint16_t)(pack_bf16(t, 0.f) & 0xffff);
+                    }
+                }
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int tcx_conv3d_cl(const void* x, const void* cache, const void* w, const void* bias, const void* res, void* y,
+                             int32_t N, int32_t T_in, int32_t H_in, int32_t W_in, int32_t Cin, int32_t Cout,
+                             int32_t kT, int32_t kH, int32_t kW, int32_t T_out, int32_t ups, const int32_t* t_map,
+                             void* stream) {
+    TCX_CHECK(x && w && y, TCX_E_NULL, "tcx_conv3d_cl: null x/w/y");
+    TCX_CHECK(N > 0 && T_in > 0 && H_in > 0 && W_in > 0 && Cin > 0 && Cout > 0 && T_out > 0, TCX_E_SHAPE, "tcx_conv3d_cl: empty shape");
+    TCX_CHECK(Cin % 8 == 0, TCX_E_SHAPE, "tcx_conv3d_cl: Cin (%d) must be a multiple of 8 (pad channels on the host)", Cin);
+    TCX_CHECK(kT >= 1 && kT <= 3 && (kH == 1 || kH == 3) && (kW == 1 || kW == 3), TCX_E_SHAPE, "tcx_conv3d_cl: kernel %dx%dx%d unsupported", kT, kH, kW);
+    TCX_CHECK(ups == 0 || ups == 1, TCX_E_SHAPE, "tcx_conv3d_cl: ups must be 0 or 1");
+    TCX_CHECK(t_map != nullptr || T_out == T_in, TCX_E_SHAPE, "tcx_conv3d_cl: T_out (%d) != T_in (%d) needs a t_map", T_out, T_in);
+    TCX_CHECK(!(kT > 1 && t_map), TCX_E_SHAPE, "tcx_conv3d_cl: t_map is only supported with kT == 1");
+    TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(cache) && tcx_aligned16(w) && tcx_aligned16(y) && tcx_aligned16(res) &&
+                  (reinterpret_cast<uintptr_t>(bias) & 7) == 0,
+              TCX_E_ALIGN, "tcx_conv3d_cl: pointers must be 16-byte aligned (bias 8)");
+    ConvParams p;
+    p.x = (const uint16_t*)x; p.cache = (const uint16_t*)cache; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias;
+    p.res = (const uint16_t*)res; p.y = (uint16_t*)y; p.t_map = t_map;
+    p.N = N; p.T_in = T_in; p.H_in = H_in; p.W_in = W_in; p.Cin = Cin; p.Cout = Cout; p.kT = kT; p.kH = kH; p.kW = kW;
+    p.T_out = T_out; p.H = H_in << ups; p.W = W_in << ups; p.ups = ups;
+    p.Ktot = kT * kH * kW * Cin;
+    p.M = (int64_t)N * T_out * p.H * p.W;
+    p.ntn = (uint32_t)((Cout + BN - 1) / BN);
+    const int64_t nwg = ((p.M + BM - 1) / BM) * p.ntn;
+    TCX_CHECK(nwg < (1ll << 31), TCX_E_SHAPE, "tcx_conv3d_cl: grid too large");
+    p.nwg = (uint32_t)nwg;
+    hipLaunchKernelGGL(conv_igemm_kernel, dim3(p.nwg), dim3(256), 0, (hipStream_t)stream, p);
+    TCX_LAUNCH_RET();
+}

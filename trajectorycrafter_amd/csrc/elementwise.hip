@@ -1,0 +1,284 @@
+// HBM-bound elementwise / gather kernels (gfx950): K5 gated residual, K6 bias+GELU(tanh) epilogue,
+// K8 patchify / unpatchify, K10 CFG + DDIM step, K14 layout changes.  16-byte vector accesses,
+// fp32 arithmetic, one rounding at the store; grids capped and grid-strided.
+#include "tcx_common.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 256 * 8;
+
+inline unsigned grid_for(int64_t nvec, int threads = 256) {
+    int64_t b = (nvec + threads - 1) / threads;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// x[b, r, :] += gate[b, :] * y[b, r, :]
+__global__ __launch_bounds__(256) void gated_residual_kernel(uint16_t* x, const uint16_t* y, int32_t rows, int32_t C,
+                                                            int64_t xsb, int64_t ysb, const uint16_t* gate_v,
+                                                            const uint16_t* gate_t, int64_t gsb, int32_t text_len) {
+    const int b = blockIdx.y;
+    const int cpr = C >> 3;                       // chunks per row
+    const int64_t nchunk = (int64_t)rows * cpr;
+    uint16_t* xb = x + (int64_t)b * xsb;
+    const uint16_t* yb = y + (int64_t)b * ysb;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunk; i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / cpr), ch = (int)(i - (int64_t)row * cpr);
+        float xv[8], yv[8], g[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xb + i * 8), xv);
+        unpack8(*reinterpret_cast<const u32x4*>(yb + i * 8), yv);
+        const uint16_t* gp = row < text_len ? gate_t : gate_v;
+        if (gp) {
+            unpack8(*reinterpret_cast<const u32x4*>(gp + (int64_t)b * gsb + 8 * ch), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(g[e], yv[e], xv[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = xv[e] + yv[e];
+        }
+        *reinterpret_cast<u32x4*>(xb + i * 8) = pack8(o);
+    }
+}
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))),  tanh(u) = 1 - 2 / (1 + e^{2u})
+    const float u = 0.7978845608028654f * __builtin_fmaf(0.044715f * x * x, x, x);
+    const float e = __expf(2.0f * u);
+    const float t = 1.0f - 2.0f / (1.0f + e);
+    return 0.5f * x * (1.0f + t);
+}
+
+__global__ __launch_bounds__(256) void bias_gelu_kernel(const uint16_t* x, const uint16_t* bias, uint16_t* y,
+                                                        int64_t nchunk, int32_t cpr) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunk; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8], bb[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), v);
+        if (bias) {
+            unpack8(*reinterpret_cast<const u32x4*>(bias + 8 * (i % cpr)), bb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bb[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = gelu_tanh(v[e]);
+        *reinterpret_cast<u32x4*>(y + i * 8) = pack8(o);
+    }
+}
+
+template <int OP>  // 0: scale, 1: silu
+__global__ __launch_bounds__(256) void unary_kernel(const uint16_t* x, uint16_t* y, int64_t n, float s) {
+    const int64_t nchunk = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunk; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = OP == 0 ? v[e] * s : v[e] / (1.0f + __expf(-v[e]));
+        *reinterpret_cast<u32x4*>(y + i * 8) = pack8(o);
+    }
+    // ragged tail (n % 8) handled by the first threads
+    const int64_t tail0 = nchunk << 3;
+    const int64_t t = tail0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        const float v = bf16_bits_to_f32(x[t]);
+        const float o = OP == 0 ? v * s : v / (1.0f + __expf(-v));
+        y[t] = (uint16_t)(pack_bf16(o, 0.f) & 0xffff);
+    }
+}
+
+// out[(b,f,gy,gx), (c,ky,kx)] = in[b,f,c, gy*p+ky, gx*p+kx], c over the concat of a (Ca ch) and b (Cb ch)
+__global__ __launch_bounds__(256) void patchify_kernel(const uint16_t* a, const uint16_t* bsrc, uint16_t* out,
+                                                       int32_t BF, int32_t Ca, int32_t Cb, int32_t H, int32_t W, int32_t p) {
+    const int gh = H / p, gw = W / p, Ct = Ca + Cb, K = Ct * p * p;
+    const int64_t n = (int64_t)BF * gh * gw * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % K);
+        const int64_t m = i / K;
+        const int gx = (int)(m % gw), gy = (int)((m / gw) % gh);
+        const int64_t bf = m / ((int64_t)gw * gh);
+        const int kx = kk % p, ky = (kk / p) % p, c = kk / (p * p);
+        const int yy = gy * p + ky, xx = gx * p + kx;
+        uint16_t v;
+        if (c < Ca) v = a[((bf * Ca + c) * H + yy) * W + xx];
+        else v = bsrc[((bf * Cb + (c - Ca)) * H + yy) * W + xx];
+        out[i] = v;
+    }
+}
+
+// out[b,f,c, gy*p+py, gx*p+px] = x[b, (f,gy,gx), (c,py,px)]
+template <bool F32>
+__global__ __launch_bounds__(256) void unpatchify_kernel(const uint16_t* x, void* out, int32_t BF, int32_t C, int32_t H,
+                                                         int32_t W, int32_t p) {
+    const int gh = H / p, gw = W / p;
+    const int64_t n = (int64_t)BF * C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W), yy = (int)((i / W) % H);
+        const int c = (int)((i / ((int64_t)W * H)) % C);
+        const int64_t bf = i / ((int64_t)W * H * C);
+        const int gy = yy / p, py = yy % p, gx = xx / p, px = xx % p;
+        const uint16_t v = x[((bf * gh + gy) * gw + gx) * ((int64_t)C * p * p) + (c * p + py) * p + px];
+        if constexpr (F32) reinterpret_cast<float*>(out)[i] = bf16_bits_to_f32(v);
+        else reinterpret_cast<uint16_t*>(out)[i] = v;
+    }
+}
+
+template <bool PRED_F32>
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(const void* u, const void* c, const uint16_t* x, uint16_t* out,
+                                                       int64_t n, float g, float sa, float sb, float sap, float sbp) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float uu, cc = 0.f;
+        if constexpr (PRED_F32) {
+            uu = reinterpret_cast<const float*>(u)[i];
+            if (c) cc = reinterpret_cast<const float*>(c)[i];
+        } else {
+            uu = bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(u)[i]);
+            if (c) cc = bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(c)[i]);
+        }
+        const float noise = c ? uu + g * (cc - uu) : uu;
+        const float xs = bf16_bits_to_f32(x[i]);
+        // 0-dim fp32 scalar * bf16 tensor stays bf16 in the reference (SURVEY 8c promotion quirk)
+        const float x0 = round_bf16(sa * xs) - sb * noise;
+        const float eps = sa * noise + round_bf16(sb * xs);
+        const float prev = sap * x0 + sbp * eps;
+        out[i] = (uint16_t)(pack_bf16(prev, 0.f) & 0xffff);
+    }
+}
+
+// [N, C, S] (S = T*H*W) bf16 -> channels-last [N, S, C] bf16, scaled by `mul`; LDS-tiled transpose
+__global__ __launch_bounds__(256) void ncthw_to_cl_kernel(const uint16_t* x, uint16_t* y, int32_t C, int64_t S, float mul) {
+    __shared__ uint16_t tile[32][33];
+    const int n = blockIdx.z;
+    const int64_t s0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const uint16_t* xn = x + (int64_t)n * C * S;
+    uint16_t* yn = y + (int64_t)n * C * S;
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j;
+        const int64_t s = s0 + tx;
+        tile[j][tx] = (c < C && s < S) ? xn[(int64_t)c * S + s] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t s = s0 + j;
+        const int c = c0 + tx;
+        if (c < C && s < S) {
+            const float v = bf16_bits_to_f32(tile[tx][j]) * mul;
+            yn[s * C + c] = (uint16_t)(pack_bf16(v, 0.f) & 0xffff);
+        }
+    }
+}
+
+// channels-last [N, S, C] bf16 -> frames fp32: y[n, c, out_offset + s] = clamp(x/2 + .5, 0, 1)
+__global__ __launch_bounds__(256) void cl_to_frames_kernel(const uint16_t* x, float* y, int32_t C, int64_t S,
+                                                           int64_t out_sstride, int64_t out_off) {
+    const int n = blockIdx.y;
+    const int64_t total = S * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / C;
+        const int c = (int)(i - s * C);
+        // bf16 rounding of (x/2 + 0.5) first: the reference computes it in the VAE dtype (bf16)
+        float v = round_bf16(bf16_bits_to_f32(x[(int64_t)n * total + i]) * 0.5f + 0.5f);
+        v = fminf(fmaxf(v, 0.f), 1.f);
+        y[((int64_t)n * C + c) * out_sstride + out_off + s] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int tcx_gated_residual(void* x, const void* y, int32_t B, int32_t rows, int32_t C, int64_t xsb, int64_t ysb,
+                                  const void* gate_v, const void* gate_t, int64_t gsb, int32_t text_len, void* stream) {
+    TCX_CHECK(x && y, TCX_E_NULL, "tcx_gated_residual: null x/y");
+    TCX_CHECK(B > 0 && B < 65536 && rows > 0 && C > 0 && C % 8 == 0, TCX_E_SHAPE, "tcx_gated_residual: bad shape B=%d rows=%d C=%d", B, rows, C);
+    TCX_CHECK(xsb % 8 == 0 && ysb % 8 == 0 && gsb % 8 == 0, TCX_E_ALIGN, "tcx_gated_residual: strides must be multiples of 8");
+    TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(y) && tcx_aligned16(gate_v) && tcx_aligned16(gate_t), TCX_E_ALIGN,
+              "tcx_gated_residual: pointers must be 16-byte aligned");
+    if (text_len > 0) TCX_CHECK((gate_t != nullptr) == (gate_v != nullptr), TCX_E_NULL, "tcx_gated_residual: gate_t must be given iff gate_v is");
+    const int64_t nchunk = (int64_t)rows * (C / 8);
+    dim3 grid(grid_for(nchunk), B);
+    hipLaunchKernelGGL(gated_residual_kernel, grid, dim3(256), 0, (hipStream_t)stream, (uint16_t*)x, (const uint16_t*)y, rows, C,
+                       xsb, ysb, (const uint16_t*)gate_v, (const uint16_t*)gate_t, gsb, text_len);
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_bias_gelu_tanh(const void* x, const void* bias, void* y, int64_t rows, int32_t C, void* stream) {
+    TCX_CHECK(x && y, TCX_E_NULL, "tcx_bias_gelu_tanh: null x/y");
+    TCX_CHECK(rows > 0 && C > 0 && C % 8 == 0, TCX_E_SHAPE, "tcx_bias_gelu_tanh: bad shape rows=%lld C=%d", (long long)rows, C);
+    TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(y) && tcx_aligned16(bias), TCX_E_ALIGN, "tcx_bias_gelu_tanh: pointers must be 16-byte aligned");
+    const int64_t nchunk = rows * (C / 8);
+    hipLaunchKernelGGL(bias_gelu_kernel, dim3(grid_for(nchunk)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                       (const uint16_t*)bias, (uint16_t*)y, nchunk, C / 8);
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_scale_bf16(const void* x, void* y, int64_t n, float s, void* stream) {
+    TCX_CHECK(x && y, TCX_E_NULL, "tcx_scale_bf16: null pointer");
+    TCX_CHECK(n > 0, TCX_E_SHAPE, "tcx_scale_bf16: n must be positive");
+    TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(y), TCX_E_ALIGN, "tcx_scale_bf16: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(unary_kernel<0>, dim3(grid_for((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, n, s);
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_silu_bf16(const void* x, void* y, int64_t n, void* stream) {
+    TCX_CHECK(x && y, TCX_E_NULL, "tcx_silu_bf16: null pointer");
+    TCX_CHECK(n > 0, TCX_E_SHAPE, "tcx_silu_bf16: n must be positive");
+    TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(y), TCX_E_ALIGN, "tcx_silu_bf16: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(unary_kernel<1>, dim3(grid_for((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, n, 0.f);
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_patchify(const void* a, const void* b, void* out, int32_t B, int32_t F, int32_t Ca, int32_t Cb,
+                            int32_t H, int32_t W, int32_t p, void* stream) {
+    TCX_CHECK(a && out, TCX_E_NULL, "tcx_patchify: null pointer");
+    TCX_CHECK((b != nullptr) == (Cb > 0), TCX_E_NULL, "tcx_patchify: b must be given iff Cb > 0");
+    TCX_CHECK(B > 0 && F > 0 && Ca > 0 && Cb >= 0 && p > 0 && H % p == 0 && W % p == 0, TCX_E_SHAPE,
+              "tcx_patchify: H=%d, W=%d must be divisible by patch %d", H, W, p);
+    const int64_t n = (int64_t)B * F * (H / p) * (W / p) * (Ca + Cb) * p * p;
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a,
+                       (const uint16_t*)b, (uint16_t*)out, B * F, Ca, Cb, H, W, p);
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_unpatchify(const void* x, void* out, int32_t B, int32_t F, int32_t C, int32_t H, int32_t W, int32_t p,
+                              int32_t out_dtype, void* stream) {
+    TCX_CHECK(x && out, TCX_E_NULL, "tcx_unpatchify: null pointer");
+    TCX_CHECK(B > 0 && F > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0, TCX_E_SHAPE, "tcx_unpatchify: bad shape");
+    TCX_CHECK(out_dtype == TCX_BF16 || out_dtype == TCX_F32, TCX_E_DTYPE, "tcx_unpatchify: bad out_dtype %d", out_dtype);
+    const int64_t n = (int64_t)B * F * C * H * W;
+    if (out_dtype == TCX_F32)
+        hipLaunchKernelGGL(unpatchify_kernel<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, out, B * F, C, H, W, p);
+    else
+        hipLaunchKernelGGL(unpatchify_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, out, B * F, C, H, W, p);
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_cfg_ddim_step(const void* u, const void* c, const void* x, void* out, int64_t n, float guidance,
+                                 float alpha_t, float alpha_prev, int32_t pred_dtype, void* stream) {
+    TCX_CHECK(u && x && out, TCX_E_NULL, "tcx_cfg_ddim_step: null pointer");
+    TCX_CHECK(n > 0, TCX_E_SHAPE, "tcx_cfg_ddim_step: n must be positive");
+    TCX_CHECK(pred_dtype == TCX_BF16 || pred_dtype == TCX_F32, TCX_E_DTYPE, "tcx_cfg_ddim_step: bad pred_dtype %d", pred_dtype);
+    TCX_CHECK(alpha_t >= 0.f && alpha_t <= 1.f && alpha_prev >= 0.f && alpha_prev <= 1.f, TCX_E_SHAPE, "tcx_cfg_ddim_step: alphas must be in [0,1]");
+    const float sa = sqrtf(alpha_t), sb = sqrtf(1.0f - alpha_t), sap = sqrtf(alpha_prev), sbp = sqrtf(1.0f - alpha_prev);
+    if (pred_dtype == TCX_F32)
+        hipLaunchKernelGGL(cfg_ddim_kernel<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, sa, sb, sap, sbp);
+    else
+        hipLaunchKernelGGL(cfg_ddim_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, sa, sb, sap, sbp);
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_ncthw_to_cl(const void* x, void* y, int32_t N, int32_t C, int64_t spatial, float mul, void* stream) {
+    TCX_CHECK(x && y, TCX_E_NULL, "tcx_ncthw_to_cl: null pointer");
+    TCX_CHECK(N > 0 && N < 65536 && C > 0 && spatial > 0, TCX_E_SHAPE, "tcx_ncthw_to_cl: bad shape");
+    dim3 grid((unsigned)((spatial + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
+    hipLaunchKernelGGL(ncthw_to_cl_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, C, spatial, mul);
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_cl_to_ncthw_frames(const void* x, float* y, int32_t N, int32_t C, int64_t spatial, int64_t out_sstride,
+                                      int64_t out_off, void* stream) {
+    TCX_CHECK(x && y, TCX_E_NULL, "tcx_cl_to_ncthw_frames: null pointer");
+    TCX_CHECK(N > 0 && N < 65536 && C > 0 && spatial > 0 && out_off >= 0 && out_off + spatial <= out_sstride, TCX_E_SHAPE,
+              "tcx_cl_to_ncthw_frames: bad shape");
+    dim3 grid(grid_for(spatial * C), (unsigned)N);
+    hipLaunchKernelGGL(cl_to_frames_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, y, C, spatial, out_sstride, out_off);
+    TCX_LAUNCH_RET();
+}

@@ -1,0 +1,206 @@
+// HBM-bound row kernels of the DiT blocks (gfx950): K4 LayerNorm(+AdaLN modulate) and
+// K2 per-head q/k LayerNorm + 3-D RoPE.  One 64-lane wave per row, 16-byte loads over the
+// (T*H*W, C) token-major layout, statistics and arithmetic in fp32, one rounding at the store.
+#include "tcx_common.h"
+
+namespace {
+
+struct LnParams {
+    const uint16_t* x;
+    uint16_t* y;
+    int32_t B, rows, C;
+    int64_t xsb, ysb;
+    const uint16_t *gamma, *beta, *shift_v, *scale_v, *shift_t, *scale_t;
+    int64_t msb;
+    int32_t text_len;
+    float eps;
+};
+
+// NCH = 16-byte chunks per lane (C <= NCH * 512)
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const LnParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)p.B * p.rows) return;
+    const int b = (int)(row / p.rows), rr = (int)(row - (int64_t)b * p.rows);
+    const uint16_t* xr = p.x + (int64_t)b * p.xsb + (int64_t)rr * p.C;
+    uint16_t* yr = p.y + (int64_t)b * p.ysb + (int64_t)rr * p.C;
+    const int nchunk = p.C >> 3;
+
+    float v[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = j * 64 + lane;
+        if (ch < nchunk) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(xr + 8 * ch);
+            unpack8(raw, v[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += v[j][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+        }
+    }
+    const float invC = 1.0f / (float)p.C;
+    const float mean = wave_sum(sum) * invC;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = j * 64 + lane;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[j][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) * invC + p.eps);
+
+    const bool text = rr < p.text_len;
+    const uint16_t* sh = text ? p.shift_t : p.shift_v;
+    const uint16_t* sc = text ? p.scale_t : p.scale_v;
+    if (sh) sh += (int64_t)b * p.msb;
+    if (sc) sc += (int64_t)b * p.msb;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = j * 64 + lane;
+        if (ch < nchunk) {
+            float g[8], be[8], s1[8], s2[8], out[8];
+            if (p.gamma) unpack8(*reinterpret_cast<const u32x4*>(p.gamma + 8 * ch), g);
+            if (p.beta) unpack8(*reinterpret_cast<const u32x4*>(p.beta + 8 * ch), be);
+            if (sc) unpack8(*reinterpret_cast<const u32x4*>(sc + 8 * ch), s1);
+            if (sh) unpack8(*reinterpret_cast<const u32x4*>(sh + 8 * ch), s2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = (v[j][e] - mean) * rstd;
+                if (p.gamma) t *= g[e];
+                if (p.beta) t += be[e];
+                if (sc) t *= (1.0f + s1[e]);
+                if (sh) t += s2[e];
+                out[e] = t;
+            }
+            *reinterpret_cast<u32x4*>(yr + 8 * ch) = pack8(out);
+        }
+    }
+}
+
+struct QkParams {
+    uint16_t *q, *k;
+    int32_t B, S, H;
+    int64_t sb, ss, sh;
+    const uint16_t *gq, *bq, *gk, *bk;
+    const float *cos, *sin;
+    int32_t text_len;
+    float eps;
+    int64_t nvec;
+};
+
+// 8 lanes per 64-wide head vector (8 bf16 = 16 B per lane); a wave covers 8 head vectors.
+__global__ __launch_bounds__(256) void qk_ln_rope_kernel(const QkParams p) {
+    const int lane = threadIdx.x & 63, sub = lane & 7;
+    const int64_t vec = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (lane >> 3);
+    const bool active = vec < p.nvec;
+    // vec = ((b*S + s)*2 + which)*H + h
+    const int64_t vv = active ? vec : 0;
+    const int hh = (int)(vv % p.H);
+    const int64_t t1 = vv / p.H;
+    const int which = (int)(t1 & 1);
+    const int64_t tok = t1 >> 1;
+    const int b = (int)(tok / p.S), s = (int)(tok - (int64_t)b * p.S);
+    uint16_t* base = (which ? p.k : p.q) + (int64_t)b * p.sb + (int64_t)s * p.ss + (int64_t)hh * p.sh + 8 * sub;
+    float x[8];
+    unpack8(*reinterpret_cast<const u32x4*>(base), x);
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += x[e];
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64);
+    const float mean = sum * (1.0f / 64.0f);
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float d = x[e] - mean;
+        sq += d * d;
+    }
+    sq += __shfl_xor(sq, 1, 64);
+    sq += __shfl_xor(sq, 2, 64);
+    sq += __shfl_xor(sq, 4, 64);
+    const float rstd = rsqrtf(sq * (1.0f / 64.0f) + p.eps);
+    float g[8], be[8];
+    unpack8(*reinterpret_cast<const u32x4*>((which ? p.gk : p.gq) + 8 * sub), g);
+    unpack8(*reinterpret_cast<const u32x4*>((which ? p.bk : p.bq) + 8 * sub), be);
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = (x[e] - mean) * rstd * g[e] + be[e];
+    if (p.cos && s >= p.text_len) {
+        const int64_t ro = (int64_t)(s - p.text_len) * 64 + 8 * sub;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.cos + ro), c1 = *reinterpret_cast<const f32x4*>(p.cos + ro + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.sin + ro), s1 = *reinterpret_cast<const f32x4*>(p.sin + ro + 4);
+        const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const float sn[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        float z[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // adjacent pairs (2i, 2i+1): rot = (-x_imag, x_real)
+            z[2 * i] = y[2 * i] * cs[2 * i] - y[2 * i + 1] * sn[2 * i];
+            z[2 * i + 1] = y[2 * i + 1] * cs[2 * i + 1] + y[2 * i] * sn[2 * i + 1];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = z[e];
+    }
+    if (active) *reinterpret_cast<u32x4*>(base) = pack8(y);
+}
+
+}  // namespace
+
+extern "C" int tcx_layernorm_modulate(const void* x, void* y, int32_t B, int32_t rows, int32_t C,
+                                      int64_t xsb, int64_t ysb, const void* gamma, const void* beta,
+                                      const void* shift_v, const void* scale_v, const void* shift_t,
+                                      const void* scale_t, int64_t msb, int32_t text_len, float eps, void* stream) {
+    TCX_CHECK(x && y, TCX_E_NULL, "tcx_layernorm_modulate: null x/y");
+    TCX_CHECK(B > 0 && rows > 0 && C > 0 && C % 8 == 0 && C <= 8192, TCX_E_SHAPE,
+              "tcx_layernorm_modulate: need C %% 8 == 0 and C <= 8192 (B=%d rows=%d C=%d)", B, rows, C);
+    TCX_CHECK(xsb % 8 == 0 && ysb % 8 == 0 && msb % 8 == 0, TCX_E_ALIGN, "tcx_layernorm_modulate: strides must be multiples of 8");
+    TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(y) && tcx_aligned16(gamma) && tcx_aligned16(beta) && tcx_aligned16(shift_v) &&
+                  tcx_aligned16(scale_v) && tcx_aligned16(shift_t) && tcx_aligned16(scale_t),
+              TCX_E_ALIGN, "tcx_layernorm_modulate: pointers must be 16-byte aligned");
+    if (text_len > 0)
+        TCX_CHECK((shift_t != nullptr) == (shift_v != nullptr) && (scale_t != nullptr) == (scale_v != nullptr), TCX_E_NULL,
+                  "tcx_layernorm_modulate: text modulation must be given iff video modulation is");
+    LnParams p{(const uint16_t*)x, (uint16_t*)y, B, rows, C, xsb, ysb, (const uint16_t*)gamma, (const uint16_t*)beta,
+               (const uint16_t*)shift_v, (const uint16_t*)scale_v, (const uint16_t*)shift_t, (const uint16_t*)scale_t,
+               msb, text_len, eps};
+    const int64_t total = (int64_t)B * rows;
+    dim3 grid((unsigned)((total + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = (C / 8 + 63) / 64;
+    if (nch <= 1) hipLaunchKernelGGL(ln_modulate_kernel<1>, grid, block, 0, st, p);
+    else if (nch <= 2) hipLaunchKernelGGL(ln_modulate_kernel<2>, grid, block, 0, st, p);
+    else if (nch <= 4) hipLaunchKernelGGL(ln_modulate_kernel<4>, grid, block, 0, st, p);
+    else if (nch <= 6) hipLaunchKernelGGL(ln_modulate_kernel<6>, grid, block, 0, st, p);
+    else if (nch <= 8) hipLaunchKernelGGL(ln_modulate_kernel<8>, grid, block, 0, st, p);
+    else hipLaunchKernelGGL(ln_modulate_kernel<16>, grid, block, 0, st, p);
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_qk_layernorm_rope(void* q, void* k, int32_t B, int32_t S, int32_t H, int32_t D,
+                                     int64_t sb, int64_t ss, int64_t sh,
+                                     const void* gq, const void* bq, const void* gk, const void* bk,
+                                     const float* cos, const float* sin, int32_t text_len, float eps, void* stream) {
+    TCX_CHECK(q && k && gq && bq && gk && bk, TCX_E_NULL, "tcx_qk_layernorm_rope: null pointer");
+    TCX_CHECK(D == 64, TCX_E_SHAPE, "tcx_qk_layernorm_rope: head dim must be 64 (got %d)", D);
+    TCX_CHECK(B > 0 && S > 0 && H > 0 && text_len >= 0 && text_len <= S, TCX_E_SHAPE, "tcx_qk_layernorm_rope: bad shape");
+    TCX_CHECK((cos == nullptr) == (sin == nullptr), TCX_E_NULL, "tcx_qk_layernorm_rope: cos and sin must both be given or both null");
+    TCX_CHECK(sb % 8 == 0 && ss % 8 == 0 && sh % 8 == 0, TCX_E_ALIGN, "tcx_qk_layernorm_rope: strides must be multiples of 8");
+    TCX_CHECK(tcx_aligned16(q) && tcx_aligned16(k) && tcx_aligned16(gq) && tcx_aligned16(bq) && tcx_aligned16(gk) &&
+                  tcx_aligned16(bk) && tcx_aligned16(cos) && tcx_aligned16(sin),
+              TCX_E_ALIGN, "tcx_qk_layernorm_rope: pointers must be 16-byte aligned");
+    QkParams p{(uint16_t*)q, (uint16_t*)k, B, S, H, sb, ss, sh, (const uint16_t*)gq, (const uint16_t*)bq,
+               (const uint16_t*)gk, (const uint16_t*)bk, cos, sin, text_len, eps, (int64_t)B * S * 2 * H};
+    const int64_t nblk = (p.nvec + 31) / 32;
+    TCX_CHECK(nblk < (1ll << 31), TCX_E_SHAPE, "tcx_qk_layernorm_rope: grid too large");
+    hipLaunchKernelGGL(qk_ln_rope_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+    TCX_LAUNCH_RET();
+}

@@ -1,0 +1,447 @@
+"""MI355X-native `AutoencoderKLCogVideoX` — drop-in for reference models/autoencoder_magvit.py.
+
+Same class / sub-module / parameter names (state-dict keys) and the same `encode` / `decode`
+surface (:1176-1280).  Internally activations are channels-last `[N, T, H, W, C]` bf16 (the
+"(T*H*W, C)" layout of the north star): every convolution is the hand-written implicit-GEMM MFMA
+kernel `tcx_conv3d_cl` (causal temporal context, spatial zero padding, nearest x2 upsample and the
+temporal frame map are folded into its gather, so no padded / upsampled tensor is materialised),
+GroupNorm + SpatialNorm + SiLU is one two-pass fused kernel pair, residual adds are conv epilogues.
+
+The nn.Conv3d / nn.Conv2d / nn.GroupNorm sub-modules only hold parameters; there is no torch
+fallback — CPU or non-bf16 calls raise `TcxError`.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import TcxError
+from ..config import ConfigMixin, ModelMixin, register_to_config
+
+BF16 = torch.bfloat16
+
+
+# ------------------------------------------------------------------------------ index maps
+def upsample_t_map(T: int, compress_time: bool) -> List[int]:
+    """Source frame of every output frame of diffusers CogVideoXUpsample3D (nearest in time)."""
+    if not compress_time or T == 1:
+        return list(range(T))
+    if T % 2 == 1:                                   # first frame spatial-only, the rest x2 in time
+        return [0] + [1 + j // 2 for j in range(2 * (T - 1))]
+    return [j // 2 for j in range(2 * T)]
+
+
+def zq_t_map(T: int, Tz: int) -> List[int]:
+    """zq frame for every frame of f in CogVideoXSpatialNorm3D (reference :200-208)."""
+    if T > 1 and T % 2 == 1:
+        rest = [1 + (j * (Tz - 1)) // (T - 1) for j in range(T - 1)] if Tz > 1 else [0] * (T - 1)
+        return [0] + rest
+    return [(j * Tz) // T for j in range(T)]
+
+
+_MAP_CACHE = {}
+
+
+def _dev_map(vals: List[int], device) -> torch.Tensor:
+    key = (tuple(vals), str(device))
+    t = _MAP_CACHE.get(key)
+    if t is None:
+        t = torch.tensor(vals, dtype=torch.int32, device=device)
+        _MAP_CACHE[key] = t
+    return t
+
+
+class _PermutedWeight:
+    """Lazily cached channels-last copy [Cout, kT, kH, kW, Cin] of a conv weight."""
+
+    def __init__(self):
+        self._key = None
+        self._w = None
+
+    def get(self, w: torch.Tensor) -> torch.Tensor:
+        key = (w.data_ptr(), w._version, w.dtype, w.device)
+        if self._key != key:
+            if w.dim() == 5:
+                wp = w.detach().permute(0, 2, 3, 4, 1)
+            else:                                     # Conv2d [Cout, Cin, kH, kW] -> kT = 1
+                wp = w.detach().permute(0, 2, 3, 1).unsqueeze(1)
+            cin = wp.shape[-1]
+            if cin % 8:                               # pad input channels (RGB) to a multiple of 8 with zeros
+                wp = torch.nn.functional.pad(wp, (0, 8 - cin % 8))
+            self._w = wp.contiguous()
+            self._key = key
+        return self._w
+
+
+def _pad_channels(x: torch.Tensor, mult: int = 8) -> torch.Tensor:
+    c = x.shape[-1]
+    return x if c % mult == 0 else torch.nn.functional.pad(x, (0, mult - c % mult))
+
+
+class CogVideoXSafeConv3d(nn.Conv3d):
+    """reference :41-73.  Parameter container; the >2 GiB chunking is unnecessary (no cuDNN workspace)."""
+
+    def forward_cl(self, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if not hasattr(self, "_wcl"):
+            self._wcl = _PermutedWeight()
+        return ops.conv3d_cl(x, self._wcl.get(self.weight), self.bias, res=res)
+
+
+class CogVideoXCausalConv3d(nn.Module):
+    """reference :76-163."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: Union[int, Tuple[int, int, int]], stride: int = 1,
+                 dilation: int = 1, pad_mode: str = "constant"):
+        super().__init__()
+        if isinstance(kernel_size, int):
+            kernel_size = (kernel_size,) * 3
+        if stride != 1 or dilation != 1:
+            raise ValueError("only stride=1, dilation=1 causal convolutions exist on this path")
+        self.time_kernel_size = kernel_size[0]
+        self.conv = CogVideoXSafeConv3d(in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size)
+        self.conv_cache: Optional[torch.Tensor] = None       # channels-last [N, kT-1, H, W, Cin]
+        self._wcl = _PermutedWeight()
+
+    def _clear_fake_context_parallel_cache(self):
+        self.conv_cache = None
+
+    def forward_cl(self, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+        kt = self.time_kernel_size
+        x = _pad_channels(x)
+        y = ops.conv3d_cl(x, self._wcl.get(self.conv.weight), self.conv.bias, cache=self.conv_cache, res=res)
+        if kt > 1:                                           # cache = last kT-1 logical input frames (:157)
+            if x.shape[1] >= kt - 1:
+                self.conv_cache = x[:, -(kt - 1):].contiguous()
+            else:
+                prev = self.conv_cache if self.conv_cache is not None else x[:, :1].expand(-1, kt - 1, -1, -1, -1)
+                self.conv_cache = torch.cat([prev, x], dim=1)[:, -(kt - 1):].contiguous()
+        return y
+
+
+class CogVideoXSpatialNorm3D(nn.Module):
+    """reference :166-212 (+ the SiLU its callers apply next)."""
+
+    def __init__(self, f_channels: int, zq_channels: int, groups: int = 32):
+        super().__init__()
+        self.norm_layer = nn.GroupNorm(num_channels=f_channels, num_groups=groups, eps=1e-6, affine=True)
+        self.conv_y = CogVideoXCausalConv3d(zq_channels, f_channels, kernel_size=1, stride=1)
+        self.conv_b = CogVideoXCausalConv3d(zq_channels, f_channels, kernel_size=1, stride=1)
+        self.groups = groups
+
+    def forward_cl(self, f: torch.Tensor, zq: torch.Tensor, silu: bool = True) -> torch.Tensor:
+        T, Tz = f.shape[1], zq.shape[1]
+        ytab = self.conv_y.forward_cl(zq)                     # 1x1x1 convs at zq's own resolution
+        btab = self.conv_b.forward_cl(zq)
+        stats = ops.groupnorm_stats(f, self.groups, self.norm_layer.eps)
+        tmap = _dev_map(zq_t_map(T, Tz), f.device)
+        return ops.groupnorm_apply(f, stats, self.norm_layer.weight, self.norm_layer.bias, self.groups, ytab, btab, tmap, silu)
+
+
+def _groupnorm_silu(norm: nn.GroupNorm, x: torch.Tensor) -> torch.Tensor:
+    stats = ops.groupnorm_stats(x, norm.num_groups, norm.eps)
+    return ops.groupnorm_apply(x, stats, norm.weight, norm.bias, norm.num_groups, silu=True)
+
+
+class CogVideoXResnetBlock3D(nn.Module):
+    """reference :215-355 (temb_channels = 0 on this path)."""
+
+    def __init__(self, in_channels: int, out_channels: Optional[int] = None, dropout: float = 0.0, temb_channels: int = 512,
+                 groups: int = 32, eps: float = 1e-6, non_linearity: str = "swish", conv_shortcut: bool = False,
+                 spatial_norm_dim: Optional[int] = None, pad_mode: str = "first"):
+        super().__init__()
+        out_channels = out_channels or in_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.use_conv_shortcut = conv_shortcut
+        if spatial_norm_dim is None:
+            self.norm1 = nn.GroupNorm(num_channels=in_channels, num_groups=groups, eps=eps)
+            self.norm2 = nn.GroupNorm(num_channels=out_channels, num_groups=groups, eps=eps)
+        else:
+            self.norm1 = CogVideoXSpatialNorm3D(in_channels, spatial_norm_dim, groups)
+            self.norm2 = CogVideoXSpatialNorm3D(out_channels, spatial_norm_dim, groups)
+        self.conv1 = CogVideoXCausalConv3d(in_channels, out_channels, kernel_size=3, pad_mode=pad_mode)
+        if temb_channels > 0:
+            self.temb_proj = nn.Linear(temb_channels, out_channels)
+        self.dropout = nn.Dropout(dropout)
+        self.conv2 = CogVideoXCausalConv3d(out_channels, out_channels, kernel_size=3, pad_mode=pad_mode)
+        if in_channels != out_channels:
+            if conv_shortcut:
+                self.conv_shortcut = CogVideoXCausalConv3d(in_channels, out_channels, kernel_size=3, pad_mode=pad_mode)
+            else:
+                self.conv_shortcut = CogVideoXSafeConv3d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
+
+    def forward_cl(self, x: torch.Tensor, zq: Optional[torch.Tensor] = None) -> torch.Tensor:
+        h = self.norm1.forward_cl(x, zq) if zq is not None else _groupnorm_silu(self.norm1, x)       # :328-333
+        h = self.conv1.forward_cl(h)                                                                 # :334
+        h = self.norm2.forward_cl(h, zq) if zq is not None else _groupnorm_silu(self.norm2, h)       # :342-347
+        sc = x if self.in_channels == self.out_channels else self.conv_shortcut.forward_cl(x)        # :351-352
+        return self.conv2.forward_cl(h, res=sc)                                                      # :349,354 (fused add)
+
+
+class CogVideoXUpsample3D(nn.Module):
+    """diffusers CogVideoXUpsample3D: nearest x2 (+ temporal rule) fused into the 3x3 conv's gather."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 1, padding: int = 1,
+                 compress_time: bool = False):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding)
+        self.compress_time = compress_time
+        self._wcl = _PermutedWeight()
+
+    def forward_cl(self, x: torch.Tensor) -> torch.Tensor:
+        tmap = _dev_map(upsample_t_map(x.shape[1], self.compress_time), x.device)
+        return ops.conv3d_cl(x, self._wcl.get(self.conv.weight), self.conv.bias, ups=1, t_map=tmap)
+
+
+class CogVideoXDownsample3D(nn.Module):
+    """diffusers CogVideoXDownsample3D (encoder; parameters kept so checkpoints load)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 2, padding: int = 0,
+                 compress_time: bool = False):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding)
+        self.compress_time = compress_time
+
+
+class CogVideoXDownBlock3D(nn.Module):
+    """reference :358-464."""
+
+    def __init__(self, in_channels: int, out_channels: int, temb_channels: int, dropout: float = 0.0, num_layers: int = 1,
+                 resnet_eps: float = 1e-6, resnet_act_fn: str = "swish", resnet_groups: int = 32, add_downsample: bool = True,
+                 downsample_padding: int = 0, compress_time: bool = False, pad_mode: str = "first"):
+        super().__init__()
+        self.resnets = nn.ModuleList([
+            CogVideoXResnetBlock3D(in_channels if i == 0 else out_channels, out_channels, dropout, temb_channels,
+                                   resnet_groups, resnet_eps, resnet_act_fn, pad_mode=pad_mode) for i in range(num_layers)])
+        self.downsamplers = None
+        if add_downsample:
+            self.downsamplers = nn.ModuleList([CogVideoXDownsample3D(out_channels, out_channels, padding=downsample_padding,
+                                                                     compress_time=compress_time)])
+
+
+class CogVideoXMidBlock3D(nn.Module):
+    """reference :467-548."""
+
+    def __init__(self, in_channels: int, temb_channels: int, dropout: float = 0.0, num_layers: int = 1, resnet_eps: float = 1e-6,
+                 resnet_act_fn: str = "swish", resnet_groups: int = 32, spatial_norm_dim: Optional[int] = None,
+                 pad_mode: str = "first"):
+        super().__init__()
+        self.resnets = nn.ModuleList([
+            CogVideoXResnetBlock3D(in_channels, in_channels, dropout, temb_channels, resnet_groups, resnet_eps, resnet_act_fn,
+                                   spatial_norm_dim=spatial_norm_dim, pad_mode=pad_mode) for _ in range(num_layers)])
+
+    def forward_cl(self, x, zq=None):
+        for r in self.resnets:
+            x = r.forward_cl(x, zq)
+        return x
+
+
+class CogVideoXUpBlock3D(nn.Module):
+    """reference :551-660."""
+
+    def __init__(self, in_channels: int, out_channels: int, temb_channels: int, dropout: float = 0.0, num_layers: int = 1,
+                 resnet_eps: float = 1e-6, resnet_act_fn: str = "swish", resnet_groups: int = 32, spatial_norm_dim: int = 16,
+                 add_upsample: bool = True, upsample_padding: int = 1, compress_time: bool = False, pad_mode: str = "first"):
+        super().__init__()
+        self.resnets = nn.ModuleList([
+            CogVideoXResnetBlock3D(in_channels if i == 0 else out_channels, out_channels, dropout, temb_channels,
+                                   resnet_groups, resnet_eps, resnet_act_fn, spatial_norm_dim=spatial_norm_dim,
+                                   pad_mode=pad_mode) for i in range(num_layers)])
+        self.upsamplers = None
+        if add_upsample:
+            self.upsamplers = nn.ModuleList([CogVideoXUpsample3D(out_channels, out_channels, padding=upsample_padding,
+                                                                 compress_time=compress_time)])
+
+    def forward_cl(self, x, zq):
+        for r in self.resnets:
+            x = r.forward_cl(x, zq)
+        if self.upsamplers is not None:
+            for u in self.upsamplers:
+                x = u.forward_cl(x)
+        return x
+
+
+class CogVideoXEncoder3D(nn.Module):
+    """reference :663-800 (parameters; the HIP encode path is the next hot-path row)."""
+
+    def __init__(self, in_channels: int = 3, out_channels: int = 16,
+                 down_block_types: Tuple[str, ...] = ("CogVideoXDownBlock3D",) * 4,
+                 block_out_channels: Tuple[int, ...] = (128, 256, 256, 512), layers_per_block: int = 3, act_fn: str = "silu",
+                 norm_eps: float = 1e-6, norm_num_groups: int = 32, dropout: float = 0.0, pad_mode: str = "first",
+                 temporal_compression_ratio: float = 4):
+        super().__init__()
+        tlevel = int(np.log2(temporal_compression_ratio))
+        self.conv_in = CogVideoXCausalConv3d(in_channels, block_out_channels[0], kernel_size=3, pad_mode=pad_mode)
+        self.down_blocks = nn.ModuleList([])
+        output_channel = block_out_channels[0]
+        for i, _ in enumerate(down_block_types):
+            input_channel, output_channel = output_channel, block_out_channels[i]
+            self.down_blocks.append(CogVideoXDownBlock3D(
+                input_channel, output_channel, temb_channels=0, dropout=dropout, num_layers=layers_per_block,
+                resnet_eps=norm_eps, resnet_act_fn=act_fn, resnet_groups=norm_num_groups,
+                add_downsample=i != len(block_out_channels) - 1, compress_time=i < tlevel))
+        self.mid_block = CogVideoXMidBlock3D(block_out_channels[-1], temb_channels=0, dropout=dropout, num_layers=2,
+                                             resnet_eps=norm_eps, resnet_act_fn=act_fn, resnet_groups=norm_num_groups,
+                                             pad_mode=pad_mode)
+        self.norm_out = nn.GroupNorm(norm_num_groups, block_out_channels[-1], eps=1e-6)
+        self.conv_act = nn.SiLU()
+        self.conv_out = CogVideoXCausalConv3d(block_out_channels[-1], 2 * out_channels, kernel_size=3, pad_mode=pad_mode)
+
+
+class CogVideoXDecoder3D(nn.Module):
+    """reference :803-953."""
+
+    def __init__(self, in_channels: int = 16, out_channels: int = 3,
+                 up_block_types: Tuple[str, ...] = ("CogVideoXUpBlock3D",) * 4,
+                 block_out_channels: Tuple[int, ...] = (128, 256, 256, 512), layers_per_block: int = 3, act_fn: str = "silu",
+                 norm_eps: float = 1e-6, norm_num_groups: int = 32, dropout: float = 0.0, pad_mode: str = "first",
+                 temporal_compression_ratio: float = 4):
+        super().__init__()
+        rev = list(reversed(block_out_channels))
+        self.conv_in = CogVideoXCausalConv3d(in_channels, rev[0], kernel_size=3, pad_mode=pad_mode)
+        self.mid_block = CogVideoXMidBlock3D(rev[0], temb_channels=0, num_layers=2, resnet_eps=norm_eps, resnet_act_fn=act_fn,
+                                             resnet_groups=norm_num_groups, spatial_norm_dim=in_channels, pad_mode=pad_mode)
+        self.up_blocks = nn.ModuleList([])
+        output_channel = rev[0]
+        tlevel = int(np.log2(temporal_compression_ratio))
+        for i, t in enumerate(up_block_types):
+            if t != "CogVideoXUpBlock3D":
+                raise ValueError("Invalid `up_block_type` encountered. Must be `CogVideoXUpBlock3D`")
+            prev, output_channel = output_channel, rev[i]
+            self.up_blocks.append(CogVideoXUpBlock3D(
+                prev, output_channel, temb_channels=0, dropout=dropout, num_layers=layers_per_block + 1, resnet_eps=norm_eps,
+                resnet_act_fn=act_fn, resnet_groups=norm_num_groups, spatial_norm_dim=in_channels,
+                add_upsample=i != len(block_out_channels) - 1, compress_time=i < tlevel, pad_mode=pad_mode))
+        self.norm_out = CogVideoXSpatialNorm3D(rev[-1], in_channels, groups=norm_num_groups)
+        self.conv_act = nn.SiLU()
+        self.conv_out = CogVideoXCausalConv3d(rev[-1], out_channels, kernel_size=3, pad_mode=pad_mode)
+
+    def forward_cl(self, z: torch.Tensor) -> torch.Tensor:
+        """z channels-last [N,T,h,w,16] -> [N,T',8h,8w,3] (reference :917-953)."""
+        h = self.conv_in.forward_cl(z)
+        h = self.mid_block.forward_cl(h, z)
+        for up in self.up_blocks:
+            h = up.forward_cl(h, z)
+        h = self.norm_out.forward_cl(h, z, silu=True)              # norm_out + conv_act
+        return self.conv_out.forward_cl(h)
+
+
+@dataclass
+class DecoderOutput:
+    sample: torch.Tensor
+
+
+class AutoencoderKLCogVideoX(ModelMixin, ConfigMixin):
+    """reference :956-1410."""
+
+    _supports_gradient_checkpointing = False
+
+    @register_to_config
+    def __init__(
+        self,
+        in_channels: int = 3,
+        out_channels: int = 3,
+        down_block_types: Tuple[str] = ("CogVideoXDownBlock3D",) * 4,
+        up_block_types: Tuple[str] = ("CogVideoXUpBlock3D",) * 4,
+        block_out_channels: Tuple[int] = (128, 256, 256, 512),
+        latent_channels: int = 16,
+        layers_per_block: int = 3,
+        act_fn: str = "silu",
+        norm_eps: float = 1e-6,
+        norm_num_groups: int = 32,
+        temporal_compression_ratio: float = 4,
+        sample_height: int = 480,
+        sample_width: int = 720,
+        scaling_factor: float = 1.15258426,
+        shift_factor: Optional[float] = None,
+        latents_mean: Optional[Tuple[float]] = None,
+        latents_std: Optional[Tuple[float]] = None,
+        force_upcast: float = True,
+        use_quant_conv: bool = False,
+        use_post_quant_conv: bool = False,
+    ):
+        super().__init__()
+        if use_quant_conv or use_post_quant_conv:
+            raise ValueError("quant / post-quant convs are not used by CogVideoX-Fun and are not built")
+        self.encoder = CogVideoXEncoder3D(in_channels, latent_channels, tuple(down_block_types), tuple(block_out_channels),
+                                          layers_per_block, act_fn, norm_eps, norm_num_groups,
+                                          temporal_compression_ratio=temporal_compression_ratio)
+        self.decoder = CogVideoXDecoder3D(latent_channels, out_channels, tuple(up_block_types), tuple(block_out_channels),
+                                          layers_per_block, act_fn, norm_eps, norm_num_groups,
+                                          temporal_compression_ratio=temporal_compression_ratio)
+        self.quant_conv = None
+        self.post_quant_conv = None
+        self.use_slicing = False
+        self.use_tiling = False
+        self.num_latent_frames_batch_size = 2          # reference :1079
+
+    # ---- knobs kept for API compatibility (:1109-1174) ----
+    def enable_tiling(self, *a, **k):
+        raise NotImplementedError("tiled decode (:1282-1392) is off by default in the reference and not built: "
+                                  "288 GB of HBM holds the full-frame activations")
+
+    def disable_tiling(self):
+        self.use_tiling = False
+
+    def enable_slicing(self):
+        self.use_slicing = True
+
+    def disable_slicing(self):
+        self.use_slicing = False
+
+    def _clear_fake_context_parallel_cache(self):
+        for m in self.modules():
+            if isinstance(m, CogVideoXCausalConv3d):
+                m._clear_fake_context_parallel_cache()
+
+    # ---- decode (:1217-1280) ----
+    def _decode_cl(self, z: torch.Tensor, frames_out: Optional[torch.Tensor] = None):
+        """z [N,16,T,h,w] bf16 -> list of channels-last chunks (or fills `frames_out` fp32 [N,3,T',H,W])."""
+        if not z.is_cuda or z.dtype != BF16 or self.dtype != BF16:
+            raise TcxError(f"AutoencoderKLCogVideoX.decode: needs bf16 latents and weights on the GPU "
+                           f"(got {z.dtype} on {z.device}, weights {self.dtype}); no CPU fallback")
+        N, C, T, h, w = z.shape
+        zcl = ops.ncthw_to_cl(z)
+        fbs = self.num_latent_frames_batch_size
+        if T == 1:
+            bounds = [(0, 1)]
+        else:
+            rem = T % fbs
+            bounds = [(fbs * i + (0 if i == 0 else rem), fbs * (i + 1) + rem) for i in range(T // fbs)]
+        self._clear_fake_context_parallel_cache()
+        chunks, t_off = [], 0
+        for s, e in bounds:
+            d = self.decoder.forward_cl(zcl[:, s:e].contiguous())
+            if frames_out is not None:
+                ops.cl_to_frames(d, frames_out, t_off)
+                t_off += d.shape[1]
+            else:
+                chunks.append(d)
+        self._clear_fake_context_parallel_cache()
+        return chunks
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = True):
+        chunks = self._decode_cl(z)
+        dec = torch.cat(chunks, dim=1).permute(0, 4, 1, 2, 3).contiguous()          # -> [N,3,T',H,W]
+        if not return_dict:
+            return (dec,)
+        return DecoderOutput(sample=dec)
+
+    @torch.no_grad()
+    def decode_to_frames(self, z: torch.Tensor) -> torch.Tensor:
+        """decode + `(x/2+.5).clamp(0,1).float()` of pipeline decode_latents (:514-517), written chunk by chunk."""
+        N, C, T, h, w = z.shape
+        sf = 2 ** (len(self.config.block_out_channels) - 1)
+        Tout = 1 if T == 1 else (T - 1) * int(self.config.temporal_compression_ratio) + 1
+        frames = torch.empty((N, self.config.out_channels, Tout, h * sf, w * sf), device=z.device, dtype=torch.float32)
+        self._decode_cl(z, frames)
+        return frames
+
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        raise NotImplementedError("the HIP VAE encoder is the next hot-path row (SURVEY §8f-f1); pass pre-encoded "
+                                  "conditioning latents to the pipeline (`inpaint_latents=` / `ref_latents=`)")

@@ -1,0 +1,282 @@
+"""Thin torch-tensor front end over the C ABI (libtcx_hip.so).
+
+torch is used for device memory, streams and (for now) the plain library GEMMs (hipBLASLt through
+`F.linear`); every other hot-path op is a hand-written HIP kernel reached through ctypes.  Nothing
+here falls back to torch arithmetic: a missing library or a failing launch raises `TcxError`.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import TCX_BF16, TCX_F32, TcxError, check
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, name: str, dtype=BF16) -> None:
+    if not t.is_cuda:
+        raise TcxError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TcxError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+
+
+def _bshd_strides(t: torch.Tensor, name: str) -> Tuple[int, int, int]:
+    """[B, S, H, D] view -> (stride_b, stride_s, stride_h); last dim must be contiguous."""
+    if t.dim() != 4 or t.stride(3) != 1:
+        raise TcxError(f"{name}: expected a [B,S,H,D] view with contiguous D, got {tuple(t.shape)} / {t.stride()}")
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+# ----------------------------------------------------------------------------- attention
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
+             out: Optional[torch.Tensor] = None, out_dtype=BF16) -> torch.Tensor:
+    """q [B,Sq,H,D], k/v [B,Sk,H,D] bf16 views -> o [B,Sq,H,D]."""
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _need(t, n)
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    if k.shape != (B, Sk, H, D) or v.shape != (B, Sk, H, D):
+        raise TcxError(f"attn_fwd: shape mismatch q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
+    if out is None:
+        out = torch.empty((B, Sq, H, D), device=q.device, dtype=out_dtype)
+    _need(out, "out", out_dtype)
+    lib = _lib.load()
+    check(lib.tcx_attn_fwd(_p(q), _p(k), _p(v), _p(out), B, H, Sq, Sk, D,
+                           *_bshd_strides(q, "q"), *_bshd_strides(k, "k"), *_bshd_strides(v, "v"),
+                           *_bshd_strides(out, "out"), float(scale),
+                           TCX_F32 if out_dtype == torch.float32 else TCX_BF16, _stream()), "tcx_attn_fwd")
+    return out
+
+
+def qk_layernorm_rope(q, k, gq, bq, gk, bk, cos, sin, text_len: int, eps: float = 1e-6) -> None:
+    """In-place per-head LayerNorm + RoPE on q, k [B,S,H,64] bf16 views."""
+    _need(q, "q"); _need(k, "k")
+    B, S, H, D = q.shape
+    sq = _bshd_strides(q, "q")
+    if _bshd_strides(k, "k") != sq or k.shape != q.shape:
+        raise TcxError("qk_layernorm_rope: q and k must share shape and strides")
+    if cos is not None:
+        _need(cos, "cos", torch.float32); _need(sin, "sin", torch.float32)
+        if cos.shape != (S - text_len, D) or not cos.is_contiguous() or not sin.is_contiguous():
+            raise TcxError(f"qk_layernorm_rope: cos/sin must be contiguous [{S - text_len},{D}], got {tuple(cos.shape)}")
+    lib = _lib.load()
+    check(lib.tcx_qk_layernorm_rope(_p(q), _p(k), B, S, H, D, *sq, _p(gq), _p(bq), _p(gk), _p(bk), _p(cos), _p(sin),
+                                    text_len, float(eps), _stream()), "tcx_qk_layernorm_rope")
+
+
+def _rows3(t: torch.Tensor, name: str) -> Tuple[int, int, int, int]:
+    """[B, rows, C] view with contiguous rows -> (B, rows, C, stride_b)."""
+    if t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+        raise TcxError(f"{name}: expected [B,rows,C] with contiguous rows, got {tuple(t.shape)} / {t.stride()}")
+    return t.shape[0], t.shape[1], t.shape[2], t.stride(0)
+
+
+def layernorm_modulate(x, gamma, beta, eps: float, shift_v=None, scale_v=None, shift_t=None, scale_t=None,
+                       text_len: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = LN(x)*gamma+beta [* (1+scale) + shift]; modulation vectors are [B, C] views (row stride free)."""
+    _need(x, "x")
+    B, rows, Cc, xsb = _rows3(x, "x")
+    if out is None:
+        out = torch.empty((B, rows, Cc), device=x.device, dtype=BF16)
+    _, _, _, ysb = _rows3(out, "out")
+    msb = 0
+    for m in (shift_v, scale_v, shift_t, scale_t):
+        if m is not None:
+            _need(m, "modulation")
+            if m.shape != (B, Cc) or m.stride(1) != 1:
+                raise TcxError(f"layernorm_modulate: modulation must be [B,C] with contiguous C, got {tuple(m.shape)}")
+            if msb not in (0, m.stride(0)):
+                raise TcxError("layernorm_modulate: modulation vectors must share one batch stride")
+            msb = m.stride(0)
+    lib = _lib.load()
+    check(lib.tcx_layernorm_modulate(_p(x), _p(out), B, rows, Cc, xsb, ysb, _p(gamma), _p(beta), _p(shift_v), _p(scale_v),
+                                     _p(shift_t), _p(scale_t), msb, text_len, float(eps), _stream()), "tcx_layernorm_modulate")
+    return out
+
+
+def gated_residual_(x, y, gate_v=None, gate_t=None, text_len: int = 0) -> torch.Tensor:
+    """x += gate * y in place (gate [B,C] views, text rows first)."""
+    _need(x, "x"); _need(y, "y")
+    B, rows, Cc, xsb = _rows3(x, "x")
+    By, rowsy, Cy, ysb = _rows3(y, "y")
+    if (By, rowsy, Cy) != (B, rows, Cc):
+        raise TcxError(f"gated_residual_: shape mismatch {tuple(x.shape)} vs {tuple(y.shape)}")
+    gsb = 0
+    for g in (gate_v, gate_t):
+        if g is not None:
+            _need(g, "gate")
+            if g.shape != (B, Cc) or g.stride(1) != 1:
+                raise TcxError("gated_residual_: gate must be [B,C] with contiguous C")
+            gsb = g.stride(0)
+    lib = _lib.load()
+    check(lib.tcx_gated_residual(_p(x), _p(y), B, rows, Cc, xsb, ysb, _p(gate_v), _p(gate_t), gsb, text_len, _stream()),
+          "tcx_gated_residual")
+    return x
+
+
+def bias_gelu_tanh_(x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need(x, "x")
+    if not x.is_contiguous():
+        raise TcxError("bias_gelu_tanh_: x must be contiguous")
+    Cc = x.shape[-1]
+    lib = _lib.load()
+    check(lib.tcx_bias_gelu_tanh(_p(x), _p(bias), _p(x), x.numel() // Cc, Cc, _stream()), "tcx_bias_gelu_tanh")
+    return x
+
+
+def scale_bf16(x: torch.Tensor, s: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need(x, "x")
+    if not x.is_contiguous():
+        raise TcxError("scale_bf16: x must be contiguous")
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.load().tcx_scale_bf16(_p(x), _p(out), x.numel(), float(s), _stream()), "tcx_scale_bf16")
+    return out
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    _need(x, "x")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(_lib.load().tcx_silu_bf16(_p(x), _p(out), x.numel(), _stream()), "tcx_silu_bf16")
+    return out
+
+
+def patchify(a: torch.Tensor, b: Optional[torch.Tensor], p: int) -> torch.Tensor:
+    """[B,F,Ca,H,W] (+ [B,F,Cb,H,W]) -> [B*F*(H/p)*(W/p), (Ca+Cb)*p*p]."""
+    _need(a, "a")
+    a = a.contiguous()
+    B, F, Ca, H, W = a.shape
+    Cb = 0
+    if b is not None:
+        _need(b, "b")
+        b = b.contiguous()
+        if b.shape[:2] != (B, F) or b.shape[3:] != (H, W):
+            raise TcxError(f"patchify: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+        Cb = b.shape[2]
+    out = torch.empty((B * F * (H // p) * (W // p), (Ca + Cb) * p * p), device=a.device, dtype=BF16)
+    check(_lib.load().tcx_patchify(_p(a), _p(b), _p(out), B, F, Ca, Cb, H, W, p, _stream()), "tcx_patchify")
+    return out
+
+
+def unpatchify(x: torch.Tensor, B: int, F: int, Cout: int, H: int, W: int, p: int, out_dtype=BF16) -> torch.Tensor:
+    _need(x, "x")
+    x = x.contiguous()
+    out = torch.empty((B, F, Cout, H, W), device=x.device, dtype=out_dtype)
+    check(_lib.load().tcx_unpatchify(_p(x), _p(out), B, F, Cout, H, W, p,
+                                     TCX_F32 if out_dtype == torch.float32 else TCX_BF16, _stream()), "tcx_unpatchify")
+    return out
+
+
+def cfg_ddim_step(uncond: torch.Tensor, cond: Optional[torch.Tensor], x: torch.Tensor, guidance: float,
+                  alpha_t: float, alpha_prev: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need(x, "x")
+    if uncond.dtype not in (BF16, torch.float32):
+        raise TcxError(f"cfg_ddim_step: prediction dtype {uncond.dtype} unsupported")
+    if not (uncond.is_contiguous() and x.is_contiguous() and (cond is None or cond.is_contiguous())):
+        raise TcxError("cfg_ddim_step: tensors must be contiguous")
+    if uncond.numel() != x.numel() or (cond is not None and (cond.numel() != x.numel() or cond.dtype != uncond.dtype)):
+        raise TcxError("cfg_ddim_step: size / dtype mismatch")
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.load().tcx_cfg_ddim_step(_p(uncond), _p(cond), _p(x), _p(out), x.numel(), float(guidance), float(alpha_t),
+                                        float(alpha_prev), TCX_F32 if uncond.dtype == torch.float32 else TCX_BF16, _stream()),
+          "tcx_cfg_ddim_step")
+    return out
+
+
+# ----------------------------------------------------------------------------- VAE (channels-last [N,T,H,W,C])
+def conv3d_cl(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], cache: Optional[torch.Tensor] = None,
+              res: Optional[torch.Tensor] = None, ups: int = 0, t_map: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [N,T,H,W,Cin], w [Cout,kT,kH,kW,Cin] (pre-permuted), cache [N,kT-1,H,W,Cin] -> y [N,T',H',W',Cout]."""
+    _need(x, "x"); _need(w, "w")
+    if not (x.is_contiguous() and w.is_contiguous()):
+        raise TcxError("conv3d_cl: x and w must be contiguous")
+    N, T, H, W, Cin = x.shape
+    Cout, kT, kH, kW, Cin2 = w.shape
+    if Cin2 != Cin:
+        raise TcxError(f"conv3d_cl: Cin mismatch {Cin} vs {Cin2}")
+    T_out = T if t_map is None else t_map.numel()
+    if cache is not None:
+        _need(cache, "cache")
+        if tuple(cache.shape) != (N, kT - 1, H, W, Cin) or not cache.is_contiguous():
+            raise TcxError(f"conv3d_cl: cache must be contiguous [N,{kT - 1},H,W,Cin], got {tuple(cache.shape)}")
+    if t_map is not None and (t_map.dtype != torch.int32 or not t_map.is_cuda):
+        raise TcxError("conv3d_cl: t_map must be a GPU int32 tensor")
+    y = torch.empty((N, T_out, H << ups, W << ups, Cout), device=x.device, dtype=BF16)
+    if res is not None:
+        _need(res, "res")
+        if res.shape != y.shape or not res.is_contiguous():
+            raise TcxError(f"conv3d_cl: residual must be contiguous {tuple(y.shape)}, got {tuple(res.shape)}")
+    check(_lib.load().tcx_conv3d_cl(_p(x), _p(cache), _p(w), _p(bias), _p(res), _p(y), N, T, H, W, Cin, Cout, kT, kH, kW,
+                                    T_out, ups, _p(t_map), _stream()), "tcx_conv3d_cl")
+    return y
+
+
+def linear_hip(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x @ w.T + bias (+ res) through the hand-written implicit-GEMM kernel (1x1x1 convolution)."""
+    Cout, Cin = w.shape
+    xs = x.reshape(1, 1, 1, -1, Cin)
+    r = None if res is None else res.reshape(1, 1, 1, -1, Cout)
+    y = conv3d_cl(xs, w.reshape(Cout, 1, 1, 1, Cin), bias, res=r)
+    return y.reshape(*x.shape[:-1], Cout)
+
+
+def groupnorm_stats(x: torch.Tensor, groups: int, eps: float) -> torch.Tensor:
+    """x [N,T,H,W,C] channels-last -> stats fp32 [N,G,2] (mean, rstd)."""
+    _need(x, "x")
+    N, Cc = x.shape[0], x.shape[-1]
+    S = x.numel() // (N * Cc)
+    nsplit = int(max(1, min(512, S // 256)))
+    stats = torch.empty((N, groups, 2), device=x.device, dtype=torch.float32)
+    partial = torch.empty((N, nsplit, 2, Cc), device=x.device, dtype=torch.float32)
+    check(_lib.load().tcx_groupnorm_stats(_p(x), _p(stats), _p(partial), N, S, Cc, groups, float(eps), nsplit, _stream()),
+          "tcx_groupnorm_stats")
+    return stats
+
+
+def groupnorm_apply(x, stats, gn_w, gn_b, groups: int, ytab=None, btab=None, z_t_map=None, silu: bool = True,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need(x, "x")
+    N, T, H, W, Cc = x.shape
+    Tz = Hz = Wz = 0
+    if ytab is not None:
+        _need(ytab, "ytab"); _need(btab, "btab")
+        if ytab.shape != btab.shape or ytab.shape[0] != N or ytab.shape[-1] != Cc:
+            raise TcxError("groupnorm_apply: bad modulation tables")
+        Tz, Hz, Wz = ytab.shape[1:4]
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.load().tcx_groupnorm_spatialnorm_silu(_p(x), _p(out), _p(stats), _p(gn_w), _p(gn_b), _p(ytab), _p(btab),
+                                                     N, T, H, W, Cc, groups, Tz, Hz, Wz, _p(z_t_map), int(silu), _stream()),
+          "tcx_groupnorm_spatialnorm_silu")
+    return out
+
+
+def ncthw_to_cl(x: torch.Tensor, mul: float = 1.0) -> torch.Tensor:
+    """[N,C,T,H,W] bf16 -> channels-last [N,T,H,W,C] bf16 (scaled by mul)."""
+    _need(x, "x")
+    x = x.contiguous()
+    N, Cc, T, H, W = x.shape
+    y = torch.empty((N, T, H, W, Cc), device=x.device, dtype=BF16)
+    check(_lib.load().tcx_ncthw_to_cl(_p(x), _p(y), N, Cc, T * H * W, float(mul), _stream()), "tcx_ncthw_to_cl")
+    return y
+
+
+def cl_to_frames(x: torch.Tensor, out: torch.Tensor, t_offset: int) -> None:
+    """channels-last [N,T,H,W,C] bf16 -> out[:, :, t_offset:t_offset+T] fp32 = clamp(x/2+.5, 0, 1); out [N,C,Ttot,H,W]."""
+    _need(x, "x"); _need(out, "out", torch.float32)
+    N, T, H, W, Cc = x.shape
+    if out.shape[0] != N or out.shape[1] != Cc or out.shape[3:] != (H, W) or not out.is_contiguous():
+        raise TcxError("cl_to_frames: bad output tensor")
+    check(_lib.load().tcx_cl_to_ncthw_frames(_p(x), _p(out), N, Cc, T * H * W, out.shape[2] * H * W, t_offset * H * W,
+                                             _stream()), "tcx_cl_to_ncthw_frames")
