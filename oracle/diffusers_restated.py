@@ -123,12 +123,20 @@ def apply_rotary_emb(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> t
 # attention (call site: crosstransformer3d.py:199-208, 239-243)
 # ---------------------------------------------------------------------------
 def sdpa(p: Prec, q, k, v, scale: float) -> torch.Tensor:
-    """softmax(q k^T * scale) v with fp32 scores/softmax and P rounded to the activation dtype
-    before PV (flash-attention practice; SURVEY §8c rounding contract)."""
+    """softmax(q k^T * scale) v with fp32 scores.
+
+    Rounding contract of the HIP flash kernel (bf16 mode): the UNNORMALISED probabilities
+    e = exp(s - rowmax) are rounded to the activation dtype before PV and the row sum l is taken from
+    the unrounded e in fp32 (flash-attention practice; SURVEY §8c "P rounded to bf16 before PV").
+    The reference's eager execution (bf16_ref mode) rounds the normalised softmax instead
+    (crosstransformer3d.py:394-395 under autocast; SDPA-flash inside diffusers).  fp32 mode: no rounding.
+    """
     s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * scale
-    pr = torch.softmax(s, dim=-1)
-    pr = p.R(pr)
-    return torch.matmul(pr, v.float())
+    if p.mode == "bf16_ref":
+        return torch.matmul(p.R(torch.softmax(s, dim=-1)), v.float())
+    e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+    l = e.sum(dim=-1, keepdim=True)
+    return torch.matmul(p.R(e), v.float()) / l
 
 
 def cogvideox_attention(p: Prec, sd: dict, prefix: str, hidden, encoder, heads: int,

@@ -53,10 +53,12 @@ def perceiver_cross_attention(p: Prec, sd: dict, prefix: str, x, latents, heads:
     q, k, v = split(q), split(k), split(v)
     s = 1.0 / (dim_head ** 0.25)
     qs, ks = p.R(q * s), p.R(k * s)
-    w = torch.matmul(qs, ks.transpose(-1, -2))
-    w = p.r(w)                                   # the reference materialises bf16 scores
-    w = p.R(torch.softmax(w, dim=-1))
-    o = p.R(torch.matmul(w, v))
+    if p.mode == "bf16_ref":
+        w = p.r(torch.matmul(qs, ks.transpose(-1, -2)))          # the reference materialises bf16 scores (:392)
+        o = torch.matmul(p.R(torch.softmax(w, dim=-1)), v)       # :394-395
+    else:
+        o = dr.sdpa(p, qs, ks, v, 1.0)                           # flash contract, scores never leave fp32
+    o = p.R(o)
     o = o.permute(0, 2, 1, 3).reshape(B, S, -1)
     return p.linear(o, sd[prefix + "to_out.weight"])
 

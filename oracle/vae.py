@@ -56,8 +56,9 @@ def spatial_norm3d(p: Prec, sd: dict, prefix: str, f, zq, groups: int, cache: di
     nf = F.group_norm(f.float(), groups, p.param(sd[prefix + "norm_layer.weight"]),
                       p.param(sd[prefix + "norm_layer.bias"]), eps=1e-6)
     nf = p.r(nf)
-    y = p.r(F.conv3d(zq.float(), p.param(sd[prefix + "conv_y.conv.weight"]), p.param(sd[prefix + "conv_y.conv.bias"])))
-    bb = p.r(F.conv3d(zq.float(), p.param(sd[prefix + "conv_b.conv.weight"]), p.param(sd[prefix + "conv_b.conv.bias"])))
+    # contract points: the HIP path materialises conv_y(zq) / conv_b(zq) as bf16 tables (at zq's resolution)
+    y = p.R(F.conv3d(zq.float(), p.param(sd[prefix + "conv_y.conv.weight"]), p.param(sd[prefix + "conv_y.conv.bias"])))
+    bb = p.R(F.conv3d(zq.float(), p.param(sd[prefix + "conv_b.conv.weight"]), p.param(sd[prefix + "conv_b.conv.bias"])))
     out = p.r(p.r(nf * y) + bb)
     if silu:
         out = F.silu(out)

@@ -317,7 +317,7 @@ def install_scaffolding():
 TINY_TR = dict(num_attention_heads=2, attention_head_dim=64, in_channels=33, out_channels=16, num_layers=2,
                text_embed_dim=32, time_embed_dim=32, max_text_seq_length=10, sample_width=12, sample_height=8,
                sample_frames=9, use_rotary_positional_embeddings=True, is_train_cross=True,
-               cross_attn_in_channels=16, cross_attn_interval=2, cross_attn_dim_head=32, cross_attn_num_heads=2)
+               cross_attn_in_channels=16, cross_attn_interval=2, cross_attn_dim_head=64, cross_attn_num_heads=2)
 TINY_VAE = dict(block_out_channels=(8, 16, 16, 32), norm_num_groups=4, layers_per_block=1)
 
 
