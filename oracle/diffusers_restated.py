@@ -131,6 +131,10 @@ def sdpa(p: Prec, q, k, v, scale: float) -> torch.Tensor:
     The reference's eager execution (bf16_ref mode) rounds the normalised softmax instead
     (crosstransformer3d.py:394-395 under autocast; SDPA-flash inside diffusers).  fp32 mode: no rounding.
     """
+    if q.shape[0] * q.shape[1] > 1 and q.shape[0] * q.shape[1] * q.shape[-2] * k.shape[-2] > (1 << 29):
+        # bound the score matrix (full-size CPU baseline: 48 x 17776^2 fp32 would be 60 GB): one head at a time
+        return torch.stack([torch.stack([sdpa(p, q[b:b + 1, h:h + 1], k[b:b + 1, h:h + 1], v[b:b + 1, h:h + 1], scale)[0, 0]
+                                         for h in range(q.shape[1])]) for b in range(q.shape[0])])
     s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * scale
     if p.mode == "bf16_ref":
         return torch.matmul(p.R(torch.softmax(s, dim=-1)), v.float())

@@ -1,0 +1,125 @@
+#!/usr/bin/env python
+"""Per-kernel microbenchmarks at the 49f 480x720 shapes (B = 2, CFG).  GPU only.
+
+    python tools/microbench.py [attn] [cross] [gemm] [rows] [conv] [--iters N]
+
+Prints one line per kernel: median ms, achieved TFLOP/s or GB/s, fraction of the MI355X roofline
+(2.5 PFLOP/s dense bf16 MFMA, 8 TB/s HBM).  Timing: HIP events on the launch stream, random data.
+"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from trajectorycrafter_amd import ops  # noqa: E402
+
+BF = torch.bfloat16
+PEAK_TF, PEAK_GBS = 2500.0, 8000.0
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def report(name, ms, flops=None, bytes_=None):
+    s = f"{name:<44s} {ms:9.3f} ms"
+    if flops:
+        tf = flops / ms / 1e9
+        s += f"  {tf:8.1f} TFLOP/s  {tf / PEAK_TF:6.1%} of MFMA peak"
+    if bytes_:
+        gb = bytes_ / ms / 1e6
+        s += f"  {gb:8.1f} GB/s  {gb / PEAK_GBS:6.1%} of HBM peak"
+    print(s, flush=True)
+
+
+def main():
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["attn", "cross", "gemm", "rows", "conv"]
+    iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 10
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    rn = lambda *s: torch.randn(*s, device=dev, dtype=BF, generator=g)
+    B, S, H, D, Dm = 2, 17776, 48, 64, 3072
+    Sv, Sr = 17550, 4050
+    if "attn" in which:
+        qkv = rn(B, S, 3 * Dm)
+        q, k, v = (t.view(B, S, H, D) for t in qkv.chunk(3, -1))
+        o = torch.empty(B, S, H, D, device=dev, dtype=BF)
+        ms = timeit(lambda: ops.attn_fwd(q, k, v, 0.125, out=o), iters)
+        report("self-attn  [2,48,17776,64] (fused qkv views)", ms, flops=4.0 * S * S * Dm * B)
+        qc, kc, vc = (t.contiguous() for t in (q, k, v))
+        ms = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(
+            qc.transpose(1, 2), kc.transpose(1, 2), vc.transpose(1, 2)), max(3, iters // 2))
+        report("  torch SDPA same shape (library reference)", ms, flops=4.0 * S * S * Dm * B)
+    if "cross" in which:
+        q = rn(B, Sv, 16, 128)
+        kv = rn(B, Sr, 2 * 2048)
+        k, v = (t.view(B, Sr, 16, 128) for t in kv.chunk(2, -1))
+        kk = k.contiguous()
+        ms = timeit(lambda: ops.attn_fwd(q, kk, v, 1.0), iters)
+        report("cross-attn q[2,16,17550,128] kv[.,4050,.]", ms, flops=4.0 * Sv * Sr * 2048 * B)
+    if "gemm" in which:
+        x = rn(B * S, Dm)
+        for name, N, K in (("qkv  3072->9216", 9216, 3072), ("out  3072->3072", 3072, 3072), ("ff1  3072->12288", 12288, 3072),
+                           ("ff2 12288->3072", 3072, 12288)):
+            w = rn(N, K) * 0.02
+            xx = x if K == Dm else rn(B * S, K)
+            ms = timeit(lambda: torch.nn.functional.linear(xx, w), iters)
+            report(f"hipBLASLt {name} M={B * S}", ms, flops=2.0 * B * S * N * K)
+            if os.environ.get("TCX_BENCH_HIPGEMM", "1") == "1":
+                ms = timeit(lambda: ops.linear_hip(xx, w), max(3, iters // 2))
+                report(f"  hand igemm {name}", ms, flops=2.0 * B * S * N * K)
+    if "rows" in which:
+        x = rn(B, S, Dm)
+        gam, bet = rn(Dm), rn(Dm)
+        mod = rn(B, 6 * Dm)
+        sh, sc, gt, esh, esc, egt = mod.chunk(6, 1)
+        y = torch.empty_like(x)
+        ms = timeit(lambda: ops.layernorm_modulate(x, gam, bet, 1e-5, sh, sc, esh, esc, 226, out=y), iters)
+        report("layernorm+modulate [2,17776,3072]", ms, bytes_=2.0 * x.numel() * 2)
+        ms = timeit(lambda: ops.gated_residual_(x, y, gt, egt, 226), iters)
+        report("gated residual     [2,17776,3072]", ms, bytes_=3.0 * x.numel() * 2)
+        qkv = rn(B, S, 3 * Dm)
+        q, k, v = (t.view(B, S, H, D) for t in qkv.chunk(3, -1))
+        cos, sin = torch.rand(Sv, 64, device=dev), torch.rand(Sv, 64, device=dev)
+        g64 = rn(64)
+        ms = timeit(lambda: ops.qk_layernorm_rope(q, k, g64, g64, g64, g64, cos, sin, 226), iters)
+        report("qk layernorm+rope  [2,17776,48,64] x2", ms, bytes_=2.0 * 2 * B * S * Dm * 2)
+        hmid = rn(B * S, 4 * Dm)
+        b4 = rn(4 * Dm)
+        ms = timeit(lambda: ops.bias_gelu_tanh_(hmid, b4), iters)
+        report("bias+gelu(tanh)    [35552,12288]", ms, bytes_=2.0 * hmid.numel() * 2)
+    if "conv" in which:
+        for name, T, Hh, Ww, Ci, Co in (("up3 res 256->128 [8,480,720]", 8, 480, 720, 256, 128),
+                                       ("up2 res 256->256 [8,240,360]", 8, 240, 360, 256, 256),
+                                       ("up0 res 512->512 [2,60,90]", 2, 60, 90, 512, 512)):
+            x = rn(1, T, Hh, Ww, Ci)
+            w = rn(Co, 3, 3, 3, Ci) * 0.02
+            bia = rn(Co)
+            cache = rn(1, 2, Hh, Ww, Ci)
+            ms = timeit(lambda: ops.conv3d_cl(x, w, bia, cache=cache), max(3, iters // 2))
+            report(f"conv3d {name}", ms, flops=2.0 * 27 * Ci * Co * T * Hh * Ww)
+            st = None
+            ms = timeit(lambda: ops.groupnorm_stats(x, 32, 1e-6), max(3, iters // 2))
+            report(f"  groupnorm stats  C={Ci}", ms, bytes_=x.numel() * 2)
+            st = ops.groupnorm_stats(x, 32, 1e-6)
+            ms = timeit(lambda: ops.groupnorm_apply(x, st, bia[:0].new_ones(Ci), bia[:0].new_zeros(Ci), 32), max(3, iters // 2))
+            report(f"  groupnorm apply+silu C={Ci}", ms, bytes_=2.0 * x.numel() * 2)
+            del x, w, cache
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,68 @@
+"""Data-parallel runner: independent trajectories / clips sharded over the GPUs of one node.
+
+The reference runs the 8 orbit variants of one clip sequentially on one GPU
+(inference_orbits.py:274-300) or as separate single-GPU SLURM array tasks
+(slurm_run_orbits_auto.sh:23-30): the units are mutually independent, so the path shards with NO
+data-path collective during denoising.  One process per GPU (torchrun / torch.distributed, backend
+"nccl" = RCCL over xGMI); rank r owns trajectories r, r+W, ...; a single all-gather at the end
+reassembles the decoded frames (or the latents) on every rank.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    rank, world, local = env_rank()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Round-robin ownership: trajectory i belongs to rank i % world."""
+    return list(range(rank, n_items, world))
+
+
+def all_gather_cat(local: torch.Tensor) -> torch.Tensor:
+    """Single all-gather of equally shaped per-rank tensors -> concatenation in rank order."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    local = local.contiguous()
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local)
+    return out
+
+
+def run_trajectories(run_one: Callable[[int], torch.Tensor], n_items: int, gather: bool = True) -> torch.Tensor:
+    """Run `run_one(i)` (-> tensor [1, ...]) for the trajectories this rank owns and all-gather.
+
+    With n_items a multiple of the world size the result on every rank is `[n_items, ...]` ordered by
+    trajectory index (rank-major gather re-ordered to trajectory order)."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    if n_items % world != 0:
+        raise ValueError(f"n_items ({n_items}) must be a multiple of the world size ({world}) for a single all-gather")
+    mine = shard_indices(n_items, rank, world)
+    local = torch.cat([run_one(i) for i in mine], dim=0)
+    if not gather or world == 1:
+        return local
+    allr = all_gather_cat(local)                       # [world * per, ...] rank-major
+    per = len(mine)
+    order = [r * per + j for j in range(per) for r in range(world)]    # trajectory index i = j*world + r
+    return allr[torch.tensor(order, device=allr.device)]

@@ -399,13 +399,13 @@ class AutoencoderKLCogVideoX(ModelMixin, ConfigMixin):
                 m._clear_fake_context_parallel_cache()
 
     # ---- decode (:1217-1280) ----
-    def _decode_cl(self, z: torch.Tensor, frames_out: Optional[torch.Tensor] = None):
+    def _decode_cl(self, z: torch.Tensor, frames_out: Optional[torch.Tensor] = None, scale: float = 1.0):
         """z [N,16,T,h,w] bf16 -> list of channels-last chunks (or fills `frames_out` fp32 [N,3,T',H,W])."""
         if not z.is_cuda or z.dtype != BF16 or self.dtype != BF16:
             raise TcxError(f"AutoencoderKLCogVideoX.decode: needs bf16 latents and weights on the GPU "
                            f"(got {z.dtype} on {z.device}, weights {self.dtype}); no CPU fallback")
         N, C, T, h, w = z.shape
-        zcl = ops.ncthw_to_cl(z)
+        zcl = ops.ncthw_to_cl(z, scale)          # layout change + the 1/scaling_factor of decode_latents (:512), one rounding
         fbs = self.num_latent_frames_batch_size
         if T == 1:
             bounds = [(0, 1)]
@@ -433,13 +433,13 @@ class AutoencoderKLCogVideoX(ModelMixin, ConfigMixin):
         return DecoderOutput(sample=dec)
 
     @torch.no_grad()
-    def decode_to_frames(self, z: torch.Tensor) -> torch.Tensor:
+    def decode_to_frames(self, z: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
         """decode + `(x/2+.5).clamp(0,1).float()` of pipeline decode_latents (:514-517), written chunk by chunk."""
         N, C, T, h, w = z.shape
         sf = 2 ** (len(self.config.block_out_channels) - 1)
         Tout = 1 if T == 1 else (T - 1) * int(self.config.temporal_compression_ratio) + 1
         frames = torch.empty((N, self.config.out_channels, Tout, h * sf, w * sf), device=z.device, dtype=torch.float32)
-        self._decode_cl(z, frames)
+        self._decode_cl(z, frames, scale)
         return frames
 
     def encode(self, x: torch.Tensor, return_dict: bool = True):

@@ -1,0 +1,381 @@
+"""MI355X-native `TrajCrafter_Pipeline` — drop-in for reference models/pipeline_trajectorycrafter.py.
+
+Same constructor (:204-246) and `__call__` signature (:674-709); the 50-step loop (:1089-1198) runs
+the HIP-backed `CrossTransformer3DModel`, the fused CFG + DDIM kernel and the HIP VAE decoder.
+Nothing on this path syncs with the host inside the loop (timesteps / alphas are host scalars).
+
+Two extension kwargs (ignored by reference callers): `inpaint_latents=` and `ref_latents=` take
+pre-encoded conditioning (what :875-897 / :927-1028 build through `vae.encode`), because the HIP VAE
+*encoder* is the next hot-path row; without them and without an encoder the call
+raises instead of silently running torch.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from .._lib import TcxError
+from ..scheduler import DDIMScheduler
+
+BF16 = torch.bfloat16
+
+
+def get_resize_crop_region_for_grid(src, tgt_width, tgt_height):
+    """reference :43-58."""
+    tw, th = tgt_width, tgt_height
+    h, w = src
+    r = h / w
+    if r > (th / tw):
+        resize_height = th
+        resize_width = int(round(th / h * w))
+    else:
+        resize_width = tw
+        resize_height = int(round(tw / w * h))
+    crop_top = int(round((th - resize_height) / 2.0))
+    crop_left = int(round((tw - resize_width) / 2.0))
+    return (crop_top, crop_left), (crop_top + resize_height, crop_left + resize_width)
+
+
+def get_3d_rotary_pos_embed(embed_dim: int, crops_coords, grid_size, temporal_size: int, theta: float = 10000.0):
+    """diffusers get_3d_rotary_pos_embed(use_real=True): (cos, sin) fp32 [T*H*W, embed_dim], built on the host."""
+    start, stop = crops_coords
+    gh, gw = grid_size
+    grid_h = np.linspace(start[0], stop[0], gh, endpoint=False, dtype=np.float32)
+    grid_w = np.linspace(start[1], stop[1], gw, endpoint=False, dtype=np.float32)
+    grid_t = np.linspace(0, temporal_size, temporal_size, endpoint=False, dtype=np.float32)
+    dim_t, dim_h, dim_w = embed_dim // 4, embed_dim // 8 * 3, embed_dim // 8 * 3
+
+    def axis(pos, dim):
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float32)[: dim // 2] / dim))
+        return torch.outer(torch.from_numpy(pos).float(), freqs).repeat_interleave(2, dim=-1)
+
+    ft, fh, fw = axis(grid_t, dim_t), axis(grid_h, dim_h), axis(grid_w, dim_w)
+    T = temporal_size
+    freqs = torch.cat([ft[:, None, None, :].expand(T, gh, gw, dim_t), fh[None, :, None, :].expand(T, gh, gw, dim_h),
+                       fw[None, None, :, :].expand(T, gh, gw, dim_w)], dim=-1).reshape(T * gh * gw, -1)
+    return freqs.cos().contiguous(), freqs.sin().contiguous()
+
+
+def resize_mask(mask, latent, process_first_frame_only=True):
+    """reference :127-160."""
+    latent_size = latent.size()
+    if process_first_frame_only:
+        target_size = list(latent_size[2:])
+        target_size[0] = 1
+        first = F.interpolate(mask[:, :, 0:1], size=target_size, mode="trilinear", align_corners=False)
+        target_size = list(latent_size[2:])
+        target_size[0] = target_size[0] - 1
+        if target_size[0] != 0:
+            rest = F.interpolate(mask[:, :, 1:], size=target_size, mode="trilinear", align_corners=False)
+            return torch.cat([first, rest], dim=2)
+        return first
+    return F.interpolate(mask, size=list(latent_size[2:]), mode="trilinear", align_corners=False)
+
+
+@dataclass
+class CogVideoX_Fun_PipelineOutput:
+    """reference :178-190."""
+    videos: torch.Tensor
+
+
+class TrajCrafter_Pipeline:
+    """reference :193-1216."""
+
+    _optional_components: List[str] = []
+    model_cpu_offload_seq = "text_encoder->transformer->vae"
+    _callback_tensor_inputs = ["latents", "prompt_embeds", "negative_prompt_embeds"]
+
+    def __init__(self, tokenizer=None, text_encoder=None, vae=None, transformer=None, scheduler=None):
+        self.tokenizer, self.text_encoder = tokenizer, text_encoder
+        self.vae, self.transformer = vae, transformer
+        self.scheduler = scheduler if scheduler is not None else DDIMScheduler()
+        self.vae_scale_factor_spatial = 2 ** (len(self.vae.config.block_out_channels) - 1) if vae is not None else 8
+        self.vae_scale_factor_temporal = int(self.vae.config.temporal_compression_ratio) if vae is not None else 4
+        self.vae_scale_factor = self.vae_scale_factor_spatial
+        self._guidance_scale, self._num_timesteps, self._interrupt = 6.0, 0, False
+        self.last_timings: Dict[str, float] = {}
+
+    # ---- plumbing the reference gets from DiffusionPipeline ----
+    @classmethod
+    def from_pretrained(cls, model_dir: str, vae=None, text_encoder=None, transformer=None, scheduler=None,
+                        tokenizer=None, torch_dtype=None, **kw):
+        """demo.py:659-666: components are passed in ready-made; only the scheduler may be read from disk."""
+        if scheduler is None:
+            try:
+                scheduler = DDIMScheduler.from_pretrained(model_dir, subfolder="scheduler")
+            except (FileNotFoundError, NotADirectoryError):
+                scheduler = DDIMScheduler()
+        pipe = cls(tokenizer, text_encoder, vae, transformer, scheduler)
+        return pipe.to(dtype=torch_dtype) if torch_dtype is not None else pipe
+
+    def to(self, device=None, dtype=None):
+        for m in (self.vae, self.transformer):
+            if m is not None:
+                m.to(device=device, dtype=dtype)
+        if self.text_encoder is not None and device is not None:
+            self.text_encoder.to(device)
+        return self
+
+    def enable_model_cpu_offload(self, *a, **k):
+        """demo.py:668-671 shuttles weights host<->device on every call to fit 28 GB cards; with 288 GB of
+        HBM the 12 GB of weights simply stay resident -> move once, no hooks."""
+        return self.to("cuda")
+
+    enable_sequential_cpu_offload = enable_model_cpu_offload
+
+    def maybe_free_model_hooks(self):
+        pass
+
+    @property
+    def device(self):
+        return self.transformer.device
+
+    @property
+    def dtype(self):
+        return self.transformer.dtype
+
+    _execution_device = device
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def num_timesteps(self):
+        return self._num_timesteps
+
+    @property
+    def interrupt(self):
+        return self._interrupt
+
+    # ---- prompt encoding (:248-381): conditioning I/O, runs the caller's T5 if one was given ----
+    def encode_prompt(self, prompt, negative_prompt=None, do_classifier_free_guidance=True, num_videos_per_prompt=1,
+                      prompt_embeds=None, negative_prompt_embeds=None, max_sequence_length=226, device=None, dtype=None):
+        def embed(texts):
+            if self.text_encoder is None or self.tokenizer is None:
+                raise ValueError("no text encoder: pass `prompt_embeds` / `negative_prompt_embeds` instead of `prompt`")
+            ids = self.tokenizer(texts, padding="max_length", max_length=max_sequence_length, truncation=True,
+                                 add_special_tokens=True, return_tensors="pt").input_ids
+            return self.text_encoder(ids.to(device))[0].to(dtype=dtype or self.dtype, device=device)
+
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        batch_size = len(prompt) if prompt is not None else prompt_embeds.shape[0]
+        if prompt_embeds is None:
+            prompt_embeds = embed(prompt)
+        if do_classifier_free_guidance and negative_prompt_embeds is None:
+            negative_prompt = negative_prompt or ""
+            negative_prompt = batch_size * [negative_prompt] if isinstance(negative_prompt, str) else negative_prompt
+            if batch_size != len(negative_prompt):
+                raise ValueError(f"`negative_prompt` has batch size {len(negative_prompt)}, but `prompt` has batch size "
+                                 f"{batch_size}.")
+            negative_prompt_embeds = embed(negative_prompt)
+        return prompt_embeds, negative_prompt_embeds
+
+    def check_inputs(self, prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs,
+                     prompt_embeds=None, negative_prompt_embeds=None):
+        """reference :543-599 (same conditions, same exception type)."""
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if callback_on_step_end_tensor_inputs is not None and not all(
+                k in self._callback_tensor_inputs for k in callback_on_step_end_tensor_inputs):
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in {self._callback_tensor_inputs}")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one of the two.")
+        elif prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        elif prompt is not None and (not isinstance(prompt, str) and not isinstance(prompt, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `negative_prompt_embeds`.")
+        if negative_prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError("Cannot forward both `negative_prompt` and `negative_prompt_embeds`.")
+        if prompt_embeds is not None and negative_prompt_embeds is not None:
+            if prompt_embeds.shape != negative_prompt_embeds.shape:
+                raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed directly, "
+                                 f"but got: `prompt_embeds` {prompt_embeds.shape} != `negative_prompt_embeds` "
+                                 f"{negative_prompt_embeds.shape}.")
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, video_length, dtype, device, generator,
+                        latents=None):
+        """reference :383-457 (strength == 1 branch: pure noise * init_noise_sigma)."""
+        shape = (batch_size, (video_length - 1) // self.vae_scale_factor_temporal + 1, num_channels_latents,
+                 height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective "
+                             f"batch size of {batch_size}.")
+        if latents is None:
+            gdev = generator.device if generator is not None else device
+            noise = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)     # randn_tensor
+        else:
+            if tuple(latents.shape) != shape:
+                raise ValueError(f"`latents` has shape {tuple(latents.shape)}, expected {shape}")
+            noise = latents.to(device=device, dtype=dtype)
+        return noise * self.scheduler.init_noise_sigma, noise
+
+    def _prepare_rotary_positional_embeddings(self, height: int, width: int, num_frames: int, device):
+        """reference :616-649."""
+        p = self.transformer.config.patch_size
+        gh, gw = height // (self.vae_scale_factor_spatial * p), width // (self.vae_scale_factor_spatial * p)
+        base_w, base_h = 720 // (self.vae_scale_factor_spatial * p), 480 // (self.vae_scale_factor_spatial * p)
+        crops = get_resize_crop_region_for_grid((gh, gw), base_w, base_h)
+        cos, sin = get_3d_rotary_pos_embed(self.transformer.config.attention_head_dim, crops, (gh, gw), num_frames)
+        return cos.to(device), sin.to(device)
+
+    def get_timesteps(self, num_inference_steps, strength, device=None):
+        """reference :664-671."""
+        init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+        t_start = max(num_inference_steps - init_timestep, 0)
+        return self.scheduler.timesteps[t_start * self.scheduler.order:], num_inference_steps - t_start
+
+    def decode_latents(self, latents: torch.Tensor) -> torch.Tensor:
+        """reference :508-518 -> fp32 frames [B,3,F,H,W] in [0,1] ON THE GPU (the caller decides about .cpu())."""
+        z = latents.permute(0, 2, 1, 3, 4)
+        return self.vae.decode_to_frames(z, scale=1.0 / self.vae.config.scaling_factor)
+
+    def _build_conditioning(self, video, mask_video, reference, height, width, do_cfg, dtype, device):
+        """reference :862-897, :927-1028 — needs the VAE encoder."""
+        raise NotImplementedError(
+            "building inpaint / reference latents from pixels needs the HIP VAE encoder (next hot-path row, SURVEY §8f-f1); "
+            "pass `inpaint_latents=` [2B,T,17,h,w] and `ref_latents=` [2B,Tr,16,h,w] (e.g. produced by the reference's "
+            "conditioning stage) — see INTEGRATION.md")
+
+    @torch.no_grad()
+    def __call__(
+        self,
+        prompt: Optional[Union[str, List[str]]] = None,
+        negative_prompt: Optional[Union[str, List[str]]] = None,
+        height: int = 480,
+        width: int = 720,
+        video: Optional[torch.Tensor] = None,
+        mask_video: Optional[torch.Tensor] = None,
+        reference: Optional[torch.Tensor] = None,
+        masked_video_latents: Optional[torch.Tensor] = None,
+        num_frames: int = 49,
+        num_inference_steps: int = 50,
+        timesteps: Optional[List[int]] = None,
+        guidance_scale: float = 6,
+        use_dynamic_cfg: bool = False,
+        num_videos_per_prompt: int = 1,
+        eta: float = 0.0,
+        generator: Optional[Union[torch.Generator, List[torch.Generator]]] = None,
+        latents: Optional[torch.Tensor] = None,
+        prompt_embeds: Optional[torch.Tensor] = None,
+        negative_prompt_embeds: Optional[torch.Tensor] = None,
+        output_type: str = "numpy",
+        return_dict: bool = False,
+        callback_on_step_end: Optional[Callable] = None,
+        callback_on_step_end_tensor_inputs: List[str] = ["latents"],
+        max_sequence_length: int = 226,
+        strength: float = 1,
+        noise_aug_strength: float = 0.0563,
+        comfyui_progressbar: bool = False,
+        inpaint_latents: Optional[torch.Tensor] = None,
+        ref_latents: Optional[torch.Tensor] = None,
+    ) -> CogVideoX_Fun_PipelineOutput:
+        if num_frames > 49:
+            raise ValueError("The number of frames must be less than 49 for now due to static positional embeddings. "
+                             "This will be updated in the future to remove this limitation.")
+        if eta != 0.0 or strength != 1:
+            raise ValueError("only eta = 0 and strength = 1 (the reference's inference settings) are implemented")
+        num_videos_per_prompt = 1
+        self.check_inputs(prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs, prompt_embeds,
+                          negative_prompt_embeds)
+        self._guidance_scale = guidance_scale
+        self._interrupt = False
+        device = self.device
+        if device.type != "cuda" or self.dtype != BF16:
+            raise TcxError(f"TrajCrafter_Pipeline: models must be bf16 on the GPU (got {self.dtype} on {device}); "
+                           "the HIP path has no CPU fallback")
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None:
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        do_cfg = guidance_scale > 1.0
+
+        # 3. prompt (:831-843)
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(
+            prompt, negative_prompt, do_cfg, num_videos_per_prompt, prompt_embeds, negative_prompt_embeds,
+            max_sequence_length, device)
+        prompt_embeds = prompt_embeds.to(device=device, dtype=BF16)
+        if do_cfg:
+            prompt_embeds = torch.cat([negative_prompt_embeds.to(device=device, dtype=BF16), prompt_embeds], dim=0)
+
+        # 4. timesteps (:846-850): host ints
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        timesteps, num_inference_steps = self.get_timesteps(num_inference_steps, strength, device)
+        self._num_timesteps = len(timesteps)
+
+        # 5. conditioning + latents (:862-1068)
+        if inpaint_latents is None or ref_latents is None:
+            inpaint_latents, ref_latents = self._build_conditioning(video, mask_video, reference, height, width, do_cfg,
+                                                                    BF16, device)
+        video_length = video.shape[2] if video is not None else num_frames           # quirk: real count = video.shape[2]
+        rep = 2 if do_cfg else 1
+        inpaint_latents = inpaint_latents.to(device=device, dtype=BF16)
+        ref_input = ref_latents.to(device=device, dtype=BF16)
+        if inpaint_latents.shape[0] == batch_size and rep == 2:
+            inpaint_latents = torch.cat([inpaint_latents] * 2)
+        if ref_input.shape[0] == batch_size and rep == 2:
+            ref_input = torch.cat([ref_input] * 2)
+        num_channels_latents = self.vae.config.latent_channels
+        latents, _ = self.prepare_latents(batch_size * num_videos_per_prompt, num_channels_latents, height, width,
+                                          video_length, BF16, device, generator, latents)
+        latents = latents.contiguous()
+        if inpaint_latents.shape[:2] != (rep * batch_size, latents.shape[1]) or inpaint_latents.shape[3:] != latents.shape[3:]:
+            raise ValueError(f"inpaint_latents {tuple(inpaint_latents.shape)} does not match latents {tuple(latents.shape)}")
+
+        # 7. rotary tables (:1076-1082)
+        image_rotary_emb = (self._prepare_rotary_positional_embeddings(height, width, latents.size(1), device)
+                            if self.transformer.config.use_rotary_positional_embeddings else None)
+
+        # 8. denoising loop (:1089-1198)
+        ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        ev0.record()
+        for i, t in enumerate(timesteps.tolist()):
+            if self.interrupt:
+                continue
+            latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
+            timestep = torch.full((latent_model_input.shape[0],), t, device=device, dtype=torch.int64)
+            noise_pred = self.transformer(hidden_states=latent_model_input, encoder_hidden_states=prompt_embeds,
+                                          timestep=timestep, image_rotary_emb=image_rotary_emb, return_dict=False,
+                                          inpaint_latents=inpaint_latents, cross_latents=ref_input)[0]
+            if use_dynamic_cfg:                                                        # :1142-1156
+                self._guidance_scale = 1 + guidance_scale * (
+                    (1 - math.cos(math.pi * ((num_inference_steps - t) / num_inference_steps) ** 5.0)) / 2)
+            a_t, a_prev = self.scheduler.coeffs(t)
+            if do_cfg:                                                                 # :1157-1178 fused
+                u, c = noise_pred[:batch_size], noise_pred[batch_size:]
+                latents = ops.cfg_ddim_step(u, c, latents, self.guidance_scale, a_t, a_prev)
+            else:
+                latents = ops.cfg_ddim_step(noise_pred, None, latents, 1.0, a_t, a_prev)
+            if callback_on_step_end is not None:                                       # :1181-1190
+                callback_kwargs = {k: locals()[k] for k in callback_on_step_end_tensor_inputs}
+                callback_outputs = callback_on_step_end(self, i, t, callback_kwargs)
+                latents = callback_outputs.pop("latents", latents)
+                prompt_embeds = callback_outputs.pop("prompt_embeds", prompt_embeds)
+        ev1.record()
+
+        if output_type == "latent":
+            video_out = latents
+        else:
+            video_out = self.decode_latents(latents)
+        ev2.record()
+        if output_type in ("numpy", "np"):
+            video_out = video_out.cpu()                 # reference :517 / :1214 returns a CPU float tensor
+        self._events = (ev0, ev1, ev2)
+        self.maybe_free_model_hooks()
+        return CogVideoX_Fun_PipelineOutput(videos=video_out)
+
+    def timings(self) -> Dict[str, float]:
+        """Seconds spent in the denoise loop and in the VAE decode of the last call (syncs)."""
+        ev0, ev1, ev2 = self._events
+        ev2.synchronize()
+        return {"denoise_s": ev0.elapsed_time(ev1) / 1e3, "decode_s": ev1.elapsed_time(ev2) / 1e3}

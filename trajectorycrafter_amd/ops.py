@@ -39,6 +39,23 @@ def _bshd_strides(t: torch.Tensor, name: str) -> Tuple[int, int, int]:
 
 
 # ----------------------------------------------------------------------------- attention
+_ATTN_TIMING = None      # None (off) or {head_dim: [(start_event, stop_event), ...]}
+
+
+def attn_timing_start() -> None:
+    """Bracket every tcx_attn_fwd launch with HIP events on its launch stream (bench.py roofline leg)."""
+    global _ATTN_TIMING
+    _ATTN_TIMING = {}
+
+
+def attn_timing_stop() -> dict:
+    """-> {head_dim: {"n": launches, "ms": total device milliseconds}}; synchronises."""
+    global _ATTN_TIMING
+    rec, _ATTN_TIMING = _ATTN_TIMING or {}, None
+    torch.cuda.synchronize()
+    return {d: {"n": len(ev), "ms": float(sum(a.elapsed_time(b) for a, b in ev))} for d, ev in rec.items()}
+
+
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
              out: Optional[torch.Tensor] = None, out_dtype=BF16) -> torch.Tensor:
     """q [B,Sq,H,D], k/v [B,Sk,H,D] bf16 views -> o [B,Sq,H,D]."""
@@ -52,10 +69,17 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
         out = torch.empty((B, Sq, H, D), device=q.device, dtype=out_dtype)
     _need(out, "out", out_dtype)
     lib = _lib.load()
+    ev = None
+    if _ATTN_TIMING is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     check(lib.tcx_attn_fwd(_p(q), _p(k), _p(v), _p(out), B, H, Sq, Sk, D,
                            *_bshd_strides(q, "q"), *_bshd_strides(k, "k"), *_bshd_strides(v, "v"),
                            *_bshd_strides(out, "out"), float(scale),
                            TCX_F32 if out_dtype == torch.float32 else TCX_BF16, _stream()), "tcx_attn_fwd")
+    if ev is not None:
+        ev[1].record()
+        _ATTN_TIMING.setdefault(D, []).append(ev)
     return out
 
 

@@ -1,0 +1,94 @@
+"""Host-side DDIM scheduler with the diffusers `DDIMScheduler` surface the reference pipeline uses
+(`set_timesteps`, `timesteps`, `step`, `scale_model_input`, `init_noise_sigma`, `order`, `config`).
+
+Selected by the reference at demo.py:647-657 (`DDIM_Origin`), used at
+models/pipeline_trajectorycrafter.py:846,1099,1164-1167.  The checkpoint's scheduler_config.json is
+not available offline; the defaults below are the CogVideoX-Fun-V1.1-5b-InP values as recalled
+(unverified) and every one of them is overridable / loadable from a config dict.
+
+Coefficient tables live on the host (fp32, numpy/torch CPU); the per-step tensor update is the fused
+HIP kernel `tcx_cfg_ddim_step` (CFG combine + v-prediction DDIM update + bf16 rounding).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .config import FrozenConfig
+
+
+class DDIMScheduler:
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
+                 beta_schedule: str = "scaled_linear", prediction_type: str = "v_prediction",
+                 timestep_spacing: str = "trailing", rescale_betas_zero_snr: bool = True, set_alpha_to_one: bool = True,
+                 steps_offset: int = 0, clip_sample: bool = False, **unused):
+        if beta_schedule != "scaled_linear":
+            raise ValueError(f"beta_schedule {beta_schedule!r} not supported")
+        if prediction_type != "v_prediction":
+            raise ValueError("the fused HIP step implements v_prediction (CogVideoX); got " + prediction_type)
+        if clip_sample:
+            raise ValueError("clip_sample=True is not supported")
+        self.config = FrozenConfig(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                   beta_schedule=beta_schedule, prediction_type=prediction_type,
+                                   timestep_spacing=timestep_spacing, rescale_betas_zero_snr=rescale_betas_zero_snr,
+                                   set_alpha_to_one=set_alpha_to_one, steps_offset=steps_offset, clip_sample=clip_sample)
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        if rescale_betas_zero_snr:
+            alphas = 1.0 - betas
+            abar_sqrt = torch.cumprod(alphas, dim=0).sqrt()
+            a0, aT = abar_sqrt[0].clone(), abar_sqrt[-1].clone()
+            abar_sqrt = (abar_sqrt - aT) * (a0 / (a0 - aT))
+            abar = abar_sqrt ** 2
+            alphas = torch.cat([abar[0:1], abar[1:] / abar[:-1]])
+            betas = 1 - alphas
+        self.betas = betas
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.num_inference_steps: Optional[int] = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    @classmethod
+    def from_pretrained(cls, path: str, subfolder: Optional[str] = None):
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, "scheduler_config.json")) as f:
+            return cls(**{k: v for k, v in json.load(f).items() if not k.startswith("_")})
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        N = self.config.num_train_timesteps
+        if num_inference_steps > N:
+            raise ValueError(f"num_inference_steps ({num_inference_steps}) > num_train_timesteps ({N})")
+        self.num_inference_steps = num_inference_steps
+        if self.config.timestep_spacing == "trailing":
+            ts = np.round(np.arange(N, 0, -N / num_inference_steps)).astype(np.int64) - 1
+        elif self.config.timestep_spacing == "leading":
+            ts = (np.arange(0, num_inference_steps) * (N // num_inference_steps)).round()[::-1].copy().astype(np.int64)
+            ts += self.config.steps_offset
+        else:
+            raise ValueError(f"timestep_spacing {self.config.timestep_spacing!r} not supported")
+        self.timesteps = torch.from_numpy(ts)            # host ints; the pipeline never syncs on them
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def coeffs(self, timestep: int):
+        prev = timestep - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = float(self.alphas_cumprod[timestep])
+        a_prev = float(self.alphas_cumprod[prev]) if prev >= 0 else float(self.final_alpha_cumprod)
+        return a_t, a_prev
+
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, eta: float = 0.0,
+             generator=None, return_dict: bool = False):
+        """diffusers-shaped step (no guidance): prev_sample = DDIM(model_output, sample), bf16 on the GPU."""
+        from . import ops
+        if eta != 0.0:
+            raise ValueError("only eta = 0 (deterministic DDIM) is implemented")
+        a_t, a_prev = self.coeffs(int(timestep))
+        prev = ops.cfg_ddim_step(model_output.contiguous(), None, sample.contiguous(), 1.0, a_t, a_prev)
+        return (prev,)
