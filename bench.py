@@ -91,7 +91,7 @@ def cpu_baseline(args):
 
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    cfg = dict(iw.TRANSFORMER_5B, num_layers=1)
+    cfg = dict(iw.TRANSFORMER_5B, num_layers=2)         # one block + one cross layer are timed (interval 2)
     sd = iw.random_state_dict(iw.transformer_param_shapes(dict(otr.DEFAULT_CONFIG, **cfg)), seed=0)
     T = (args.frames - 1) // 4 + 1
     gh, gw = args.height // 16, args.width // 16

@@ -20,6 +20,8 @@ import torch.nn.functional as F
 
 from .prec import Prec
 
+LOG2E = 1.4426950408889634
+
 
 # ---------------------------------------------------------------------------
 # embeddings  (call sites: reference models/crosstransformer3d.py:531-534,724-732)
@@ -143,6 +145,18 @@ def sdpa(p: Prec, q, k, v, scale: float) -> torch.Tensor:
     return torch.matmul(p.R(e), v.float()) / l
 
 
+def sdpa_log2(p: Prec, q, k, v) -> torch.Tensor:
+    """Contract of the FAST self-attention HIP path (tcx_attn_fwd with TCX_ATTN_LOG2_SCORES): q arrives
+    pre-multiplied by scale*log2(e), P = exp2(q k^T - rowmax) is rounded to the activation dtype and BOTH
+    PV and the row sum use the rounded P (the sum runs on the matrix pipe next to PV)."""
+    if q.shape[0] * q.shape[1] > 1 and q.shape[0] * q.shape[1] * q.shape[-2] * k.shape[-2] > (1 << 29):
+        return torch.stack([torch.stack([sdpa_log2(p, q[b:b + 1, h:h + 1], k[b:b + 1, h:h + 1], v[b:b + 1, h:h + 1])[0, 0]
+                                         for h in range(q.shape[1])]) for b in range(q.shape[0])])
+    s = torch.matmul(q.float(), k.float().transpose(-1, -2))
+    e = p.R(torch.exp2(s - s.amax(dim=-1, keepdim=True)))
+    return torch.matmul(e, v.float()) / e.sum(dim=-1, keepdim=True)
+
+
 def cogvideox_attention(p: Prec, sd: dict, prefix: str, hidden, encoder, heads: int,
                         rotary: Optional[Tuple[torch.Tensor, torch.Tensor]], eps: float = 1e-6):
     """diffusers `Attention` + `CogVideoXAttnProcessor2_0.__call__`; returns (video, text)."""
@@ -162,8 +176,14 @@ def cogvideox_attention(p: Prec, sd: dict, prefix: str, hidden, encoder, heads: 
         cos, sin = rotary
         q = torch.cat([q[:, :, :text_len], apply_rotary_emb(q[:, :, text_len:], cos, sin)], dim=2)
         k = torch.cat([k[:, :, :text_len], apply_rotary_emb(k[:, :, text_len:], cos, sin)], dim=2)
-    q, k = p.R(q), p.R(k)                                    # contract: fused qk-LN+RoPE output
-    o = sdpa(p, q, k, v, scale=dh ** -0.5)
+    if p.mode == "bf16":
+        # contract of the HIP path: q is stored pre-multiplied by dh^-1/2 * log2(e) (one rounding, in the fused
+        # qk-LN+RoPE kernel) and the attention kernel works on base-2 scores
+        q, k = p.R(q * (dh ** -0.5 * LOG2E)), p.R(k)
+        o = sdpa_log2(p, q, k, v)
+    else:
+        q, k = p.R(q), p.R(k)                                # reference: unscaled q, softmax(q k^T / sqrt(dh))
+        o = sdpa(p, q, k, v, scale=dh ** -0.5)
     o = p.R(o).transpose(1, 2).reshape(B, S, D)              # contract: attention output
     o = p.linear(o, sd[prefix + "to_out.0.weight"], sd.get(prefix + "to_out.0.bias"))
     return o[:, text_len:], o[:, :text_len]

@@ -37,12 +37,12 @@ def bf(t):
     return t.to(BF)
 
 
-def assert_bf16_close(got, ref, atol=1e-3, ulps=1.0, mean_frac=0.25):
+def assert_bf16_close(got, ref, atol=1e-3, ulps=1.0, mean_frac=0.25, extra=0.0):
     got, ref = got.float().cpu(), ref.float().cpu()
     assert got.shape == ref.shape, (got.shape, ref.shape)
     assert torch.isfinite(got).all()
     err = (got - ref).abs()
-    bound = ref.abs() * (2.0 ** -7) * ulps + atol
+    bound = ref.abs() * (2.0 ** -7) * ulps + atol + extra
     bad = err > bound
     assert not bad.any(), f"{int(bad.sum())}/{bad.numel()} outside 1 bf16 ulp; max err {float(err.max()):.4g}"
     scale = float(ref.abs().mean()) + 1e-6
@@ -84,7 +84,46 @@ def test_attn_fwd_matches_oracle(ops, D, B, H, Sq, Sk):
     assert_attn_close(o32, ref, bound)            # fp32 output mode
     o16 = ops.attn_fwd(dev(q), dev(k), dev(v), scale)
     assert o16.dtype == BF
-    assert_bf16_close(o16, ref)
+    assert_bf16_close(o16, ref, extra=bound)
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk", [(1, 2, 300, 333), (2, 3, 513, 64), (1, 1, 1, 1), (1, 2, 70, 129), (1, 1, 256, 2048)])
+def test_attn_fwd_log2_scores_fast_path(ops, B, H, Sq, Sk):
+    """TCX_ATTN_LOG2_SCORES (D = 64): q pre-multiplied by scale*log2(e); running max as the MFMA initial
+    accumulator; row sum of the rounded P on the matrix pipe.  Oracle: dr.sdpa_log2."""
+    D = 64
+    g = torch.Generator().manual_seed(Sq + Sk)
+    q, k, v = (bf(torch.randn(B, s, H, D, generator=g)) for s in (Sq, Sk, Sk))
+    q = bf(q.float() * (D ** -0.5 * 1.4426950408889634))
+    qt, kt, vt = q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)
+    ref = dr.sdpa_log2(Prec("bf16"), qt, kt, vt).transpose(1, 2).contiguous()
+    pr = torch.softmax(torch.matmul(qt, kt.transpose(-1, -2)) * math.log(2.0), dim=-1)
+    # P is rounded once on each side, and here the rounded P also feeds the row sum: 3 * 2^-9
+    bound = 3 * (2.0 ** -9) * torch.matmul(pr, vt.abs()).transpose(1, 2).contiguous()
+    o32 = ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, out_dtype=torch.float32, log2_scores=True)
+    assert_attn_close(o32, ref, bound)
+    o16 = ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, log2_scores=True)
+    assert_bf16_close(o16, ref, extra=bound)
+    with pytest.raises(ops.TcxError):
+        ops.attn_fwd(dev(q), dev(k), dev(v), 0.125, log2_scores=True)       # scale must be 1 with the flag
+
+
+def test_attn_fwd_fast_path_forced_recentre(ops):
+    """Rule 26 for the FAST path: scores that start very negative (first-tile re-centre with delta < 0), a
+    late spike above the deferral threshold for some rows only, and a ragged last tile."""
+    g = torch.Generator().manual_seed(17)
+    B, H, S, D = 1, 1, 64 * 5 + 9, 64
+    q, k, v = (bf(torch.randn(B, S, H, D, generator=g)) for _ in range(3))
+    q = bf(q.float() * 0.18)
+    k[0, :64, 0] = -q[0, 3, 0] * 40.0                 # row 3: every key of tile 0 scores hugely negative
+    k[0, 64 * 3 + 7, 0] = q[0, 10, 0] * 60.0          # row 10 jumps far beyond 2^6 at tile 3
+    k[0, 64 * 5 + 8, 0] = q[0, 40, 0] * 90.0          # row 40 jumps at the (ragged) last tile
+    qt, kt, vt = q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)
+    ref = dr.sdpa_log2(Prec("bf16"), qt, kt, vt).transpose(1, 2).contiguous()
+    pr = torch.softmax(torch.matmul(qt, kt.transpose(-1, -2)) * math.log(2.0), dim=-1)
+    bound = 3 * (2.0 ** -9) * torch.matmul(pr, vt.abs()).transpose(1, 2).contiguous()
+    o = ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, out_dtype=torch.float32, log2_scores=True)
+    assert_attn_close(o, ref, bound)
 
 
 def test_attn_fwd_strided_fused_qkv_views(ops):
@@ -175,6 +214,12 @@ def test_qk_layernorm_rope(ops, B, S, H, text_len):
     assert_bf16_close(dq, rq)
     assert_bf16_close(dk, rk)
     assert torch.equal(dv.cpu(), v)                      # v untouched
+    # q_scale: q (only) leaves pre-multiplied, one rounding
+    d = dev(qkv)
+    dq, dk, dv = (t.view(B, S, H, D) for t in d.chunk(3, -1))
+    ops.qk_layernorm_rope(dq, dk, dev(gq), dev(bq), dev(gk), dev(bk), dev(cos), dev(sin), text_len, 1e-6, q_scale=0.18033688)
+    assert_bf16_close(dq, rq * 0.18033688)
+    assert_bf16_close(dk, rk)
 
 
 def test_gated_residual_and_plain_residual(ops):

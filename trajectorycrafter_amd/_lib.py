@@ -10,9 +10,10 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtcx_hip.so")
+LIB_PATH = os.environ.get("TCX_LIB", os.path.join(_HERE, "libtcx_hip.so"))   # TCX_LIB: experiment builds only
 
 TCX_BF16, TCX_F32 = 0, 1
+TCX_ATTN_LOG2_SCORES = 1
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -21,8 +22,8 @@ SIGNATURES = {
     "tcx_version": [],
     "tcx_last_error_string": [],
     "tcx_device_info": [C.c_int, C.POINTER(_i32)],
-    "tcx_attn_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32] + [_i64] * 12 + [_f32, _i32, _vp],
-    "tcx_qk_layernorm_rope": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp],
+    "tcx_attn_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32] + [_i64] * 12 + [_f32, _i32, _i32, _vp],
+    "tcx_qk_layernorm_rope": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp],
     "tcx_layernorm_modulate": [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "tcx_gated_residual": [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _i64, _i32, _vp],
     "tcx_bias_gelu_tanh": [_vp, _vp, _vp, _i64, _i32, _vp],

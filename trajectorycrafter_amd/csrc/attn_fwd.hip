@@ -7,14 +7,29 @@
 // MFMA plan (v_mfma_f32_32x32x16_bf16), "swapped" so that a query row lives on ONE lane:
 //   S^T[kv, q] = K[kv, :] . Q[q, :]      A = K rows (ds_read_b128 from an XOR-swizzled LDS image)
 //                                         B = Q rows (registers for the whole kernel)
-//   -> lane (q = lane & 31) holds 2 x 16 scores of its query row: the row max is 31 v_max + one
+//   -> lane (q = lane & 31) holds 2 x 16 scores of its query row: the row max is 16 v_max3 + one
 //      v_permlane32_swap, no LDS; the row sum stays a per-lane partial until the epilogue.
 //   O^T[d, q] += V^T[d, kv] . P^T[kv, q]  B = the S^T accumulator converted to bf16 in place (an
 //                                         accumulator tile is directly the next MFMA's B operand),
 //                                         A = V^T fragments by ds_read_b64_tr_b16 (hardware
 //                                         transpose) from a row-major, XOR-swizzled V image.
-// Softmax in fp32 with exp2 and the scale folded into one FMA; the O rescale is skipped (exactly)
-// whenever no lane of the wave saw its running max move.
+//
+// The kernel is VALU-issue bound (rocprofv3: VALU active 66 % vs MFMA busy 39 % of the cycles in the
+// first version), so the loop is built to minimise VALU instructions per score element:
+//   * software pipeline — S(t+1) is issued in the same basic block as the exponentials of S(t);
+//   * the tile loop is unrolled by two so every LDS address is base-register + immediate;
+//   * K/V global loads are buffer loads: per-lane offset fixed + one scalar tile offset, rows beyond
+//     Sk return zero from the hardware range check (no 64-bit address or predicate VALU);
+//   * online softmax in fp32 with exp2 and the scale folded into one FMA; the O rescale is deferred
+//     until some row's max has grown by more than 2^6 (P <= 64 in the meantime: bf16 rounding is
+//     relative, fp32 accumulators have the head-room), which makes it rare even on random data;
+//   * FAST path (D = 64, scores already in log2 units because the q/k-LayerNorm+RoPE kernel stores q
+//     pre-multiplied by scale*log2(e)): the running max enters as the INITIAL ACCUMULATOR of the QK^T
+//     MFMA chain (a persistent register block holding -m), so P = exp2(S') needs no FMA, and the row
+//     sum is one extra MFMA per 16 keys with an all-ones A operand instead of 32 VALU adds.
+//     Per score element that leaves exp2 + 1/2 cvt_pk + 1/2 max3 on the VALU.
+#include <stdlib.h>
+#include <type_traits>
 #include "tcx_common.h"
 
 namespace {
@@ -29,6 +44,12 @@ struct AttnParams {
     float scale_log2;
     uint32_t nqb, nwg;
 };
+
+#ifndef TCX_ATTN_SUM_MFMA
+#define TCX_ATTN_SUM_MFMA 0
+#endif
+constexpr bool kSumMfma = TCX_ATTN_SUM_MFMA != 0;   // FAST path: row sum on the matrix pipe (1) or as VALU adds (0)
+constexpr float kDeferLog2 = 6.0f;   // rescale only when a row max grew by more than this (log2 units)
 
 template <int D>
 __device__ __forceinline__ int k_off(int row, int ch) {
@@ -47,12 +68,12 @@ __device__ __forceinline__ int v_chunk_off(int row, int ch) {
         return row * 256 + ((ch ^ ((row & 3) << 2)) << 4);
 }
 
-template <int D, bool OUT_F32>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
+template <int D, bool OUT_F32, bool FAST, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CH = D / 8;              // 16-B chunks per row
     constexpr int TILEB = 64 * D * 2;      // bytes of one K (or V) tile
-    constexpr int NLD = 64 * CH / 512;     // 16-B loads per thread per tile and operand
+    constexpr int NLD = 64 * CH / (64 * NW);   // 16-B loads per thread per tile and operand
     constexpr int KS = D / 16;             // k-steps of QK^T
     constexpr int DT = D / 32;             // 32-wide d tiles of O^T
 
@@ -62,10 +83,14 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
     const uint32_t id = xcd_remap(blockIdx.x, p.nwg);
     const uint32_t bh = id / p.nqb, qb = id - bh * p.nqb;
     const int b = bh / p.H, hd = bh - b * p.H;
-    const int q0 = qb * 256 + wave * 32;
+    const int q0 = qb * (32 * NW) + wave * 32;
 
+    // ---- K / V buffer descriptors: wave-uniform base, hardware range check at the end of row Sk-1 ----
     const uint16_t* kbase = p.k + (int64_t)b * p.ksb + (int64_t)hd * p.ksh;
     const uint16_t* vbase = p.v + (int64_t)b * p.vsb + (int64_t)hd * p.vsh;
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)((((int64_t)p.Sk - 1) * p.kss + D) * 2), 0x00020000);
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)((((int64_t)p.Sk - 1) * p.vss + D) * 2), 0x00020000);
+    const int ktile_bytes = (int)(64 * p.kss * 2), vtile_bytes = (int)(64 * p.vss * 2);
 
     // ---- Q fragments: B operand, lane holds Q[q0 + r][16 ks + 8 h .. +8] ----
     bf16x8 qf[KS];
@@ -77,51 +102,56 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
     }
 
-    // ---- staging: thread -> (row, chunk) of the 64-row tile ----
-    int ld_row[NLD], ld_ch[NLD];
+    // ---- staging: thread -> (row, chunk) of the 64-row tile; per-lane byte offsets are loop invariant ----
+    int kvoff[NLD], vvoff[NLD], klds[NLD], vlds[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int idx = tid + i * 512;
-        ld_row[i] = idx / CH;
-        ld_ch[i] = idx % CH;
+        const int idx = tid + i * (64 * NW);
+        const int row = idx / CH, ch = idx % CH;
+        kvoff[i] = (int)(row * p.kss * 2) + ch * 16;
+        vvoff[i] = (int)(row * p.vss * 2) + ch * 16;
+        klds[i] = k_off<D>(row, ch);
+        vlds[i] = v_chunk_off<D>(row, ch);
     }
     u32x4 kreg[NLD], vreg[NLD];
     const int ntiles = (p.Sk + 63) >> 6;
 
-    auto stage_load = [&](int tile) {
+    auto load_k = [&](int tile) {   // rows >= Sk read as zero (range check); tiles beyond the end too
+#ifdef TCX_EXP_NOLOAD
+        if (tile > 2) return;
+#endif
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int kv = tile * 64 + ld_row[i];
-            if (kv < p.Sk) {
-                kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)kv * p.kss + 8 * ld_ch[i]);
-                vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)kv * p.vss + 8 * ld_ch[i]);
-            } else {
-                kreg[i] = u32x4{0, 0, 0, 0};
-                vreg[i] = u32x4{0, 0, 0, 0};   // zero V rows so that P = 0 never meets garbage
-            }
-        }
+        for (int i = 0; i < NLD; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[i] + tile * ktile_bytes, 0, 0);
     };
-    auto stage_write = [&](int buf) {
-        char* kb = smem + buf * 2 * TILEB;
-        char* vb = kb + TILEB;
+    auto load_v = [&](int tile) {   // zero V rows beyond Sk: P = 0 never meets garbage
+#ifdef TCX_EXP_NOLOAD
+        if (tile > 2) return;
+#endif
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            *reinterpret_cast<u32x4*>(kb + k_off<D>(ld_row[i], ld_ch[i])) = kreg[i];
-            *reinterpret_cast<u32x4*>(vb + v_chunk_off<D>(ld_row[i], ld_ch[i])) = vreg[i];
-        }
+        for (int i = 0; i < NLD; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[i] + tile * vtile_bytes, 0, 0);
+    };
+    char* const kbuf0 = smem;
+    char* const vbuf0 = smem + 2 * TILEB;
+    auto write_k = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(kbuf0 + buf * TILEB + klds[i]) = kreg[i];
+    };
+    auto write_v = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(vbuf0 + buf * TILEB + vlds[i]) = vreg[i];
     };
 
-    // ---- per-lane LDS read offsets ----
-    // K (A operand of QK^T): row 32 t + r, chunk 2 ks + h
-    int koff[2][KS];
+    // ---- per-lane LDS read bases (everything else is a compile-time immediate) ----
+    // K (A operand of QK^T): row 32 t + r, chunk 2 ks + h.  t adds 32 rows = a constant; the XOR term
+    // only involves r and (2 ks + h), so one base per ks.
+    int koff[KS];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) koff[t][ks] = k_off<D>(32 * t + r, 2 * ks + h);
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = k_off<D>(r, 2 * ks + h);
+    constexpr int K_T_STRIDE = 32 * D * 2;
     // V^T (A operand of PV) via ds_read_b64_tr_b16: lane 4 q4 + pp of a 16-lane group supplies the
     // address of row (kvb + q4), columns 4 pp .. 4 pp + 3 of the group's 16-column block.
     const int gl = lane & 15, q4 = gl >> 2, pp = gl & 3, g = (lane >> 4) & 1;
-    int voff[DT];   // offset for kv block base 0 (+ 4 h), d tile dt; kv base adds a multiple of the row bytes
+    int voff[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
         const int dcol = 32 * dt + 16 * g + 4 * pp;
@@ -133,103 +163,256 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
-    float m = -INFINITY, l = 0.f;
+    float m = FAST ? 0.f : -INFINITY, l = 0.f;
     const float c = p.scale_log2;
-
-    stage_load(0);
-    stage_write(0);
-    __syncthreads();
-
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int buf = tile & 1;
-        const char* kb = smem + buf * 2 * TILEB;
-        const char* vb = kb + TILEB;
-        const bool more = tile + 1 < ntiles;
-        if (more) stage_load(tile + 1);
-
-        // ---- S^T = K Q^T ----
-        f32x16 s[2];
+    // FAST: -m replicated over an accumulator block (C-in of every S tile) and the MFMA row-sum accumulator
+    f32x16 minit, lacc;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+    for (int i = 0; i < 16; ++i) minit[i] = 0.f, lacc[i] = 0.f;
+    bf16x8 ones;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[t][i] = 0.f;
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    bool first = true;
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};   // per-lane partial row sums since the last rescale (VALU row-sum paths)
+
+    // S^T tile of one 64-key block: 2 x (32 keys x 32 queries); `ks0..ks1` selects a slice of the k-steps
+    auto qk_init = [&](f32x16 (&s)[2]) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int t = 0; t < 2; ++t) {
+            if constexpr (FAST) s[t] = minit;      // S' = K Q^T - m straight out of the MFMA chain
+            else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[t][i] = 0.f;
+            }
+        }
+    };
+    auto qk_part = [&](const char* kb, f32x16 (&s)[2], int ks0, int ks1) {
+#pragma unroll
+        for (int ks = ks0; ks < ks1; ++ks) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(kb + koff[t][ks]);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(kb + koff[ks] + t * K_T_STRIDE);
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[t], 0, 0, 0);
             }
         }
-        // ---- mask the ragged tail (keys >= Sk) ----
-        if (tile == ntiles - 1 && (p.Sk & 63)) {
-            const int kv0 = tile * 64 + 4 * h;
+    };
+
+    // running max of a freshly computed tile, then the (deferred, rare) rescale of O and l
+    auto row_max_and_rescale = [&](f32x16 (&s)[2]) {
+        float m0 = s[0][0], m1 = s[0][1], m2 = s[1][0], m3 = s[1][1];   // 4 independent v_max3 chains
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int i = 2; i < 16; i += 4) {
+            m0 = fmaxf(fmaxf(m0, s[0][i]), s[0][i + 1]);
+            m1 = fmaxf(fmaxf(m1, s[0][i + 2]), s[0][i + 3]);
+            m2 = fmaxf(fmaxf(m2, s[1][i]), s[1][i + 1]);
+            m3 = fmaxf(fmaxf(m3, s[1][i + 2]), s[1][i + 3]);
+        }
+        float mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        if constexpr (!FAST) mx *= c;
+        const uint32_t u = __float_as_uint(mx);
+        auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        if constexpr (FAST) {
+            // mx is relative to the current m (S' = S - m).  Re-centre when a row grew by more than the
+            // deferral threshold, and unconditionally on the first tile (m starts at 0).
+            if (first || !__all(mx <= kDeferLog2)) {            // wave-uniform
+                const float delta = first ? mx : fmaxf(mx, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);   // first tile: o = lacc = 0, alpha irrelevant but finite
+                m += delta;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int kv = kv0 + 32 * t + (i & 3) + 8 * (i >> 2);
-                    if (kv >= p.Sk) s[t][i] = -INFINITY;
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s[t][i] -= delta;    // this tile's scores were taken against the old m
+                if constexpr (kSumMfma) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) lacc[i] *= alpha;
+                } else {
+                    l = (l + (ls[0] + ls[1]) + (ls[2] + ls[3])) * alpha;
+                    ls[0] = ls[1] = ls[2] = ls[3] = 0.f;
                 }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) minit[i] = -m;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+                first = false;
+            }
+        } else {
+            if (!__all(mx <= m + kDeferLog2)) {   // wave-uniform.  m = -inf on the first tile -> always taken there
+                const float m_new = fmaxf(m, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m - m_new);   // exp2(-inf) = 0 on the first tile (o = l = 0)
+                l = (l + (ls[0] + ls[1]) + (ls[2] + ls[3])) * alpha;     // fold the pending partial sums, all at the old max
+                ls[0] = ls[1] = ls[2] = ls[3] = 0.f;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+                m = m_new;
+            }
         }
-        // ---- online softmax (row = lane & 31; the two half-waves hold disjoint keys of it) ----
-        float mx = s[0][0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
-        mx *= c;
-        {
-            const uint32_t u = __float_as_uint(mx);
-            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        const float m_new = fmaxf(m, mx);
-        if (!__all(m_new == m)) {   // wave-uniform; exact: alpha == 1 whenever skipped
-            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-            l *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
-            m = m_new;
-        }
-        bf16x8 pf[2][2];
-        float ls = 0.f;
+    };
+    auto mask_tail = [&](f32x16 (&s)[2]) {          // keys >= Sk of the last tile
+        const int kv0 = (ntiles - 1) * 64 + 4 * h;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][i], c, -m));
-                ls += e;
-                pf[t][i >> 3][i & 7] = (__bf16)e;
+                const int kv = kv0 + 32 * t + (i & 3) + 8 * (i >> 2);
+                if (kv >= p.Sk) s[t][i] = -INFINITY;
             }
-        l += ls;
+    };
 
-        // ---- O^T += V^T P^T ----
+    // One tile: P = exp2(.) of `cur` in four 16-key steps, each feeding its PV (and row-sum) MFMAs at
+    // once, INTERLEAVED with one quarter of the next tile's QK^T MFMAs, so that every wave's instruction
+    // stream alternates matrix and vector work (two such waves per SIMD then keep both pipes busy;
+    // bunched MFMAs made the barrier-locked partner waves collide on one pipe at a time).  The freshly
+    // finished next tile is max-checked at the end, under the tail of the PV MFMAs.
+    constexpr int KPS = KS / 4;                      // k-steps of the next tile's QK^T per 16-key step
+    // LDS -> register fragment reads of one 16-key step (issued one step ahead of their MFMAs)
+    auto read_frags = [&](auto has_next, const char* kb, const char* vb, int st, bf16x8 (&kf)[KPS][2], bf16x8 (&vf)[DT]) {
+        constexpr bool NEXT = decltype(has_next)::value;
+        if constexpr (NEXT) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
+            for (int j = 0; j < KPS; ++j)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int rowb = (32 * t + 16 * s2) * (D * 2);
-                    auto p0 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + rowb);
-                    auto p1 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + rowb + 8 * (D * 2));
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0);
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p1);
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    const s16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), pf[t][s2], o[dt], 0, 0, 0);
+                for (int t = 0; t < 2; ++t) {
+#ifdef TCX_EXP_NOLDS
+                    kf[j][t] = qf[(st + j + t) % KS];
+#else
+                    kf[j][t] = *reinterpret_cast<const bf16x8*>(kb + koff[st * KPS + j] + t * K_T_STRIDE);
+#endif
                 }
         }
+        const int rowb = (32 * (st >> 1) + 16 * (st & 1)) * (D * 2);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#ifdef TCX_EXP_NOLDS
+            vf[dt] = qf[(st + dt + 1) % KS];
+            (void)rowb;
+#else
+            auto p0 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + rowb);
+            auto p1 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + rowb + 8 * (D * 2));
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p1);
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            vf[dt] = __builtin_bit_cast(bf16x8, av);
+#endif
+        }
+    };
+    auto tile_body = [&](auto has_next, const char* kb, const char* vb, f32x16 (&cur)[2], f32x16 (&nxt)[2]) {
+        constexpr bool NEXT = decltype(has_next)::value;
+        constexpr bool PREF = (D == 64);             // D = 128 has no registers to spare for a second fragment set
+        bf16x8 kfa[KPS][2], kfb[KPS][2], vfa[DT], vfb[DT];
+        if constexpr (PREF) read_frags(has_next, kb, vb, 0, kfa, vfa);
+        if constexpr (NEXT) qk_init(nxt);
+        auto one_step = [&](int st, bf16x8 (&kf)[KPS][2], bf16x8 (&vf)[DT], bf16x8 (&kfn)[KPS][2], bf16x8 (&vfn)[DT]) {
+            const int t = st >> 1, s2 = st & 1;
+            if constexpr (PREF) {
+                if (st < 3) read_frags(has_next, kb, vb, st + 1, kfn, vfn);  // next step's operands, in flight under this step
+            } else {
+                read_frags(has_next, kb, vb, st, kf, vf);
+            }
+            if constexpr (NEXT) {
+#pragma unroll
+                for (int j = 0; j < KPS; ++j)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+                        nxt[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j][tt], qf[st * KPS + j], nxt[tt], 0, 0, 0);
+            }
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float e;
+#ifdef TCX_EXP_NOEXP
+                e = cur[t][8 * s2 + j];
+#else
+                if constexpr (FAST) {
+                    e = __builtin_amdgcn_exp2f(cur[t][8 * s2 + j]);
+                    if constexpr (!kSumMfma) ls[j & 3] += e;
+                } else {
+                    e = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[t][8 * s2 + j], c, -m));
+                    ls[j & 3] += e;
+                }
+#endif
+                pf[j] = (__bf16)e;
+            }
+#pragma unroll
+#ifdef TCX_EXP_NOPV
+            asm volatile("" ::"v"(pf), "v"(vf[0]), "v"(vf[DT - 1]));
+#else
+            for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pf, o[dt], 0, 0, 0);
+#endif
+            if constexpr (FAST && kSumMfma) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);   // row sum on the matrix pipe
+            __builtin_amdgcn_sched_barrier(0);       // keep the four steps in this order (no re-bunching)
+        };
+        if constexpr (PREF) {
+            one_step(0, kfa, vfa, kfb, vfb);
+            one_step(1, kfb, vfb, kfa, vfa);
+            one_step(2, kfa, vfa, kfb, vfb);
+            one_step(3, kfb, vfb, kfa, vfa);
+        } else {
+            one_step(0, kfa, vfa, kfa, vfa);
+            one_step(1, kfa, vfa, kfa, vfa);
+            one_step(2, kfa, vfa, kfa, vfa);
+            one_step(3, kfa, vfa, kfa, vfa);
+        }
+    };
 
-        if (more) stage_write(buf ^ 1);
+    // Software pipeline.  LDS: K and V are each double buffered but one tile apart — step(t) reads
+    // Kbuf[(t+1)&1] and Vbuf[t&1]; global loads of K[t+2] / V[t+1] are issued at the top and written after
+    // the compute; one barrier per tile.  PAR = t & 1 is a template constant (loop unrolled by two).
+    f32x16 sa[2], sb[2];
+    auto step = [&](auto par, int tile, f32x16 (&cur)[2], f32x16 (&nxt)[2]) {
+        constexpr int PAR = decltype(par)::value;
+        load_k(tile + 2);
+        load_v(tile + 1);
+        tile_body(std::true_type{}, kbuf0 + (PAR ^ 1) * TILEB, vbuf0 + PAR * TILEB, cur, nxt);
+        if (tile + 1 == ntiles - 1 && (p.Sk & 63)) mask_tail(nxt);
+        row_max_and_rescale(nxt);
+#ifndef TCX_EXP_NOWRITE
+        write_k(PAR);
+        write_v(PAR ^ 1);
+#endif
+#ifndef TCX_EXP_NOBARRIER
         __syncthreads();
+#endif
+    };
+
+    load_k(0);
+    load_v(0);
+    write_k(0);
+    write_v(0);
+    load_k(1);
+    write_k(1);
+    __syncthreads();
+    qk_init(sa);
+    qk_part(kbuf0, sa, 0, KS);
+    if (ntiles == 1 && (p.Sk & 63)) mask_tail(sa);
+    row_max_and_rescale(sa);
+    __syncthreads();                      // K[0] may be overwritten from step 0 on
+
+    int tile = 0;
+    for (; tile + 2 <= ntiles - 1; tile += 2) {
+        step(std::integral_constant<int, 0>{}, tile, sa, sb);
+        step(std::integral_constant<int, 1>{}, tile + 1, sb, sa);
     }
+    // ---- at most one more pipelined step, then the peeled last tile (no successor) ----
+    const bool odd = tile < ntiles - 1;
+    if (odd) step(std::integral_constant<int, 0>{}, tile, sa, sb);
+    f32x16 fin[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fin[t][i] = odd ? sb[t][i] : sa[t][i];
+    tile_body(std::false_type{}, kbuf0, vbuf0 + ((ntiles - 1) & 1) * TILEB, fin, sa);
+    if constexpr (!(FAST && kSumMfma)) l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
 
     // ---- epilogue: combine the two half-wave partial sums, normalise, store O[q][d] ----
-    {
+    if constexpr (FAST && kSumMfma) {
+        l = lacc[0];                      // every row of the ones-product holds the full row sum (both half-waves)
+    } else {
         const uint32_t u = __float_as_uint(l);
         auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
         l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
@@ -257,17 +440,26 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
     }
 }
 
-template <int D, bool F32>
-int launch(const AttnParams& p, hipStream_t st) {
+template <int D, bool F32, bool FAST, int NW>
+int launch_nw(AttnParams p, hipStream_t st) {
     constexpr int lds = 4 * 64 * D * 2;
     static bool attr_done = false;  // idempotent; racing threads set the same value
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, F32>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, F32, FAST, NW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<D, F32>), dim3(p.nwg), dim3(512), lds, st, p);
+    p.nqb = (uint32_t)((p.Sq + 32 * NW - 1) / (32 * NW));
+    p.nwg = p.nqb * (uint32_t)(p.B * p.H);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, F32, FAST, NW>), dim3(p.nwg), dim3(64 * NW), lds, st, p);
     TCX_LAUNCH_RET();
+}
+
+template <int D, bool F32, bool FAST>
+int launch(const AttnParams& p, hipStream_t st) {
+    static const int nw = getenv("TCX_ATTN_NW") ? atoi(getenv("TCX_ATTN_NW")) : 8;
+    if (nw == 4) return launch_nw<D, F32, FAST, 4>(p, st);
+    return launch_nw<D, F32, FAST, 8>(p, st);
 }
 
 }  // namespace
@@ -276,8 +468,11 @@ extern "C" int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o
                             int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t D,
                             int64_t qsb, int64_t qss, int64_t qsh, int64_t ksb, int64_t kss, int64_t ksh,
                             int64_t vsb, int64_t vss, int64_t vsh, int64_t osb, int64_t oss, int64_t osh,
-                            float scale, int32_t out_dtype, void* stream) {
+                            float scale, int32_t flags, int32_t out_dtype, void* stream) {
     TCX_CHECK(q && k && v && o, TCX_E_NULL, "tcx_attn_fwd: null pointer");
+    TCX_CHECK((flags & ~TCX_ATTN_LOG2_SCORES) == 0, TCX_E_SHAPE, "tcx_attn_fwd: unknown flags 0x%x", flags);
+    const bool log2s = (flags & TCX_ATTN_LOG2_SCORES) != 0;
+    TCX_CHECK(!log2s || scale == 1.0f, TCX_E_SHAPE, "tcx_attn_fwd: TCX_ATTN_LOG2_SCORES requires scale == 1 (got %g)", scale);
     TCX_CHECK(D == 64 || D == 128, TCX_E_SHAPE, "tcx_attn_fwd: head dim %d not in {64,128}", D);
     TCX_CHECK(B > 0 && H > 0 && Sq > 0 && Sk > 0, TCX_E_SHAPE, "tcx_attn_fwd: empty shape B=%d H=%d Sq=%d Sk=%d", B, H, Sq, Sk);
     TCX_CHECK(out_dtype == TCX_BF16 || out_dtype == TCX_F32, TCX_E_DTYPE, "tcx_attn_fwd: bad out_dtype %d", out_dtype);
@@ -286,17 +481,20 @@ extern "C" int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o
     const int64_t st[12] = {qsb, qss, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, oss, osh};
     for (int i = 0; i < 12; ++i)
         TCX_CHECK(st[i] % 8 == 0 && st[i] >= 0, TCX_E_ALIGN, "tcx_attn_fwd: stride %d (=%lld) must be a non-negative multiple of 8", i, (long long)st[i]);
+    TCX_CHECK(kss >= D && vss >= D, TCX_E_SHAPE, "tcx_attn_fwd: k/v row stride must be >= D");
+    // K / V of one (batch, head) are addressed with 32-bit buffer offsets (two tiles of look-ahead included)
+    TCX_CHECK(((int64_t)Sk + 192) * kss * 2 < (1ll << 31) && ((int64_t)Sk + 192) * vss * 2 < (1ll << 31), TCX_E_SHAPE,
+              "tcx_attn_fwd: Sk * row stride exceeds the 2 GiB buffer-addressing range");
     AttnParams p;
     p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.v = (const uint16_t*)v; p.o = o;
     p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk;
     p.qsb = qsb; p.qss = qss; p.qsh = qsh; p.ksb = ksb; p.kss = kss; p.ksh = ksh;
     p.vsb = vsb; p.vss = vss; p.vsh = vsh; p.osb = osb; p.oss = oss; p.osh = osh;
-    p.scale_log2 = scale * 1.4426950408889634f;
-    p.nqb = (uint32_t)((Sq + 255) / 256);
-    const uint64_t nwg = (uint64_t)p.nqb * B * H;
-    TCX_CHECK(nwg < (1ull << 31), TCX_E_SHAPE, "tcx_attn_fwd: grid too large");
-    p.nwg = (uint32_t)nwg;
+    p.scale_log2 = log2s ? 1.0f : scale * 1.4426950408889634f;
+    TCX_CHECK((uint64_t)((Sq + 127) / 128) * B * H < (1ull << 31), TCX_E_SHAPE, "tcx_attn_fwd: grid too large");
+    p.nqb = 0; p.nwg = 0;       // set per launch geometry
     hipStream_t s = (hipStream_t)stream;
-    if (D == 64) return out_dtype == TCX_F32 ? launch<64, true>(p, s) : launch<64, false>(p, s);
-    return out_dtype == TCX_F32 ? launch<128, true>(p, s) : launch<128, false>(p, s);
+    if (D == 64 && log2s) return out_dtype == TCX_F32 ? launch<64, true, true>(p, s) : launch<64, false, true>(p, s);
+    if (D == 64) return out_dtype == TCX_F32 ? launch<64, true, false>(p, s) : launch<64, false, false>(p, s);
+    return out_dtype == TCX_F32 ? launch<128, true, false>(p, s) : launch<128, false, false>(p, s);
 }

@@ -95,6 +95,7 @@ struct QkParams {
     int32_t text_len;
     float eps;
     int64_t nvec;
+    float q_scale;
 };
 
 // 8 lanes per 64-wide head vector (8 bf16 = 16 B per lane); a wave covers 8 head vectors.
@@ -150,6 +151,10 @@ __global__ __launch_bounds__(256) void qk_ln_rope_kernel(const QkParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] = z[e];
     }
+    if (!which) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] *= p.q_scale;
+    }
     if (active) *reinterpret_cast<u32x4*>(base) = pack8(y);
 }
 
@@ -188,7 +193,8 @@ extern "C" int tcx_layernorm_modulate(const void* x, void* y, int32_t B, int32_t
 extern "C" int tcx_qk_layernorm_rope(void* q, void* k, int32_t B, int32_t S, int32_t H, int32_t D,
                                      int64_t sb, int64_t ss, int64_t sh,
                                      const void* gq, const void* bq, const void* gk, const void* bk,
-                                     const float* cos, const float* sin, int32_t text_len, float eps, void* stream) {
+                                     const float* cos, const float* sin, int32_t text_len, float eps, float q_scale,
+                                     void* stream) {
     TCX_CHECK(q && k && gq && bq && gk && bk, TCX_E_NULL, "tcx_qk_layernorm_rope: null pointer");
     TCX_CHECK(D == 64, TCX_E_SHAPE, "tcx_qk_layernorm_rope: head dim must be 64 (got %d)", D);
     TCX_CHECK(B > 0 && S > 0 && H > 0 && text_len >= 0 && text_len <= S, TCX_E_SHAPE, "tcx_qk_layernorm_rope: bad shape");
@@ -198,7 +204,7 @@ extern "C" int tcx_qk_layernorm_rope(void* q, void* k, int32_t B, int32_t S, int
                   tcx_aligned16(bk) && tcx_aligned16(cos) && tcx_aligned16(sin),
               TCX_E_ALIGN, "tcx_qk_layernorm_rope: pointers must be 16-byte aligned");
     QkParams p{(uint16_t*)q, (uint16_t*)k, B, S, H, sb, ss, sh, (const uint16_t*)gq, (const uint16_t*)bq,
-               (const uint16_t*)gk, (const uint16_t*)bk, cos, sin, text_len, eps, (int64_t)B * S * 2 * H};
+               (const uint16_t*)gk, (const uint16_t*)bk, cos, sin, text_len, eps, (int64_t)B * S * 2 * H, q_scale};
     const int64_t nblk = (p.nvec + 31) / 32;
     TCX_CHECK(nblk < (1ll << 31), TCX_E_SHAPE, "tcx_qk_layernorm_rope: grid too large");
     hipLaunchKernelGGL(qk_ln_rope_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);

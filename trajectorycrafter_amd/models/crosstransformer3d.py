@@ -33,6 +33,7 @@ from .._lib import TcxError
 from ..config import ConfigMixin, ModelMixin, load_state_dict_from_dir, register_to_config
 
 BF16 = torch.bfloat16
+LOG2E = 1.4426950408889634
 
 
 @dataclass
@@ -174,9 +175,11 @@ class Attention(nn.Module):
         qkv = _linear(x_joint, w, b)                                          # [B, S, 3D]
         q, k, v = (t.view(B, S, H, dh) for t in qkv.chunk(3, dim=-1))
         cos, sin = image_rotary_emb if image_rotary_emb is not None else (None, None)
+        # q leaves the fused LN+RoPE kernel pre-multiplied by dh^-1/2 * log2(e): the attention kernel then
+        # consumes base-2 scores (P = exp2(q k^T - max)), one FMA less per score in its VALU-bound loop
         ops.qk_layernorm_rope(q, k, self.norm_q.weight, self.norm_q.bias, self.norm_k.weight, self.norm_k.bias,
-                              cos, sin, text_len, self.eps)
-        o = ops.attn_fwd(q, k, v, dh ** -0.5)                                  # [B,S,H,dh] contiguous
+                              cos, sin, text_len, self.eps, q_scale=dh ** -0.5 * LOG2E)
+        o = ops.attn_fwd(q, k, v, 1.0, log2_scores=True)                       # [B,S,H,dh] contiguous
         return _linear(o.view(B, S, D), self.to_out[0].weight, self.to_out[0].bias)
 
 

@@ -57,8 +57,10 @@ def attn_timing_stop() -> dict:
 
 
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
-             out: Optional[torch.Tensor] = None, out_dtype=BF16) -> torch.Tensor:
-    """q [B,Sq,H,D], k/v [B,Sk,H,D] bf16 views -> o [B,Sq,H,D]."""
+             out: Optional[torch.Tensor] = None, out_dtype=BF16, log2_scores: bool = False) -> torch.Tensor:
+    """q [B,Sq,H,D], k/v [B,Sk,H,D] bf16 views -> o [B,Sq,H,D].
+
+    log2_scores: q k^T already is the base-2 exponent (q pre-multiplied by scale*log2(e)); scale must be 1."""
     for n, t in (("q", q), ("k", k), ("v", v)):
         _need(t, n)
     B, Sq, H, D = q.shape
@@ -75,7 +77,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
         ev[0].record()
     check(lib.tcx_attn_fwd(_p(q), _p(k), _p(v), _p(out), B, H, Sq, Sk, D,
                            *_bshd_strides(q, "q"), *_bshd_strides(k, "k"), *_bshd_strides(v, "v"),
-                           *_bshd_strides(out, "out"), float(scale),
+                           *_bshd_strides(out, "out"), float(scale), _lib.TCX_ATTN_LOG2_SCORES if log2_scores else 0,
                            TCX_F32 if out_dtype == torch.float32 else TCX_BF16, _stream()), "tcx_attn_fwd")
     if ev is not None:
         ev[1].record()
@@ -83,8 +85,8 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
     return out
 
 
-def qk_layernorm_rope(q, k, gq, bq, gk, bk, cos, sin, text_len: int, eps: float = 1e-6) -> None:
-    """In-place per-head LayerNorm + RoPE on q, k [B,S,H,64] bf16 views."""
+def qk_layernorm_rope(q, k, gq, bq, gk, bk, cos, sin, text_len: int, eps: float = 1e-6, q_scale: float = 1.0) -> None:
+    """In-place per-head LayerNorm + RoPE on q, k [B,S,H,64] bf16 views; q additionally times q_scale."""
     _need(q, "q"); _need(k, "k")
     B, S, H, D = q.shape
     sq = _bshd_strides(q, "q")
@@ -96,7 +98,7 @@ def qk_layernorm_rope(q, k, gq, bq, gk, bk, cos, sin, text_len: int, eps: float 
             raise TcxError(f"qk_layernorm_rope: cos/sin must be contiguous [{S - text_len},{D}], got {tuple(cos.shape)}")
     lib = _lib.load()
     check(lib.tcx_qk_layernorm_rope(_p(q), _p(k), B, S, H, D, *sq, _p(gq), _p(bq), _p(gk), _p(bk), _p(cos), _p(sin),
-                                    text_len, float(eps), _stream()), "tcx_qk_layernorm_rope")
+                                    text_len, float(eps), float(q_scale), _stream()), "tcx_qk_layernorm_rope")
 
 
 def _rows3(t: torch.Tensor, name: str) -> Tuple[int, int, int, int]:
