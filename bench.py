@@ -79,39 +79,75 @@ def make_inputs(args, device, seed):
                 inpaint_latents=rn(2, T, 17, h, w), ref_latents=rn(2, 3, 16, h, w))
 
 
-def cpu_baseline(args):
-    """Oracle (CPU port of the reference, fp32) on the host cores: ONE CogVideoXBlock + ONE
-    PerceiverCrossAttention at the full 480x720 token count, B=1, then extrapolated to a clip
-    (42 blocks + 21 cross layers per forward, 100 forwards).  Reported baseline, not the target."""
-    from oracle import transformer as otr
+def cpu_baseline(args, threads: int = 16, attn_heads: int = 4, cross_heads: int = 2):
+    """Oracle (CPU port of the reference, fp32) on the host cores, bounded to ~10-30 s: at the full
+    480x720 token count, B=1, time (a) every row-wise / GEMM piece of ONE CogVideoXBlock, (b) its joint
+    attention on `attn_heads` of the 48 heads, (c) the GEMMs + LayerNorms of ONE PerceiverCrossAttention and
+    (d) its attention on `cross_heads` of the 16 heads; heads are independent, so (b) and (d) scale linearly.
+    A clip is extrapolated as 2*steps forwards x (42 blocks + 21 cross layers).  Reported baseline, not the target."""
+    import torch.nn.functional as F
     from oracle import diffusers_restated as dr
+    from oracle import transformer as otr
     from oracle.pipeline import prepare_rotary
     from oracle.prec import Prec
     from trajectorycrafter_amd import init_weights as iw
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    cfg = dict(iw.TRANSFORMER_5B, num_layers=2)         # one block + one cross layer are timed (interval 2)
-    sd = iw.random_state_dict(iw.transformer_param_shapes(dict(otr.DEFAULT_CONFIG, **cfg)), seed=0)
+    threads = max(1, min(threads, os.cpu_count() or 1))        # the box's CPU share for one GPU is 16 cores
+    torch.set_num_threads(threads)
+    cfg = dict(otr.DEFAULT_CONFIG, **dict(iw.TRANSFORMER_5B, num_layers=2))
+    sd = iw.random_state_dict(iw.transformer_param_shapes(cfg), seed=0)
     T = (args.frames - 1) // 4 + 1
     gh, gw = args.height // 16, args.width // 16
-    Sv = T * gh * gw
+    Sv, S, Sr, D = T * gh * gw, T * gh * gw + 226, 3 * gh * gw, 3072
     g = torch.Generator().manual_seed(0)
     p = Prec("fp32")
-    hidden, enc = torch.randn(1, Sv, 3072, generator=g), torch.randn(1, 226, 3072, generator=g)
-    temb, cross = torch.randn(1, 512, generator=g), torch.randn(1, 3 * gh * gw, 3072, generator=g)
-    rot = prepare_rotary(args.height, args.width, T, 2, 64)
-    t0 = time.perf_counter()
-    h, e = otr.cogvideox_block(p, sd, "transformer_blocks.0.", hidden, enc, temb, rot, 48, 1e-5)
-    t1 = time.perf_counter()
-    otr.perceiver_cross_attention(p, sd, "perceiver_cross_attention.0.", cross, h, 16, 128)
-    t2 = time.perf_counter()
-    t_fwd = 42 * (t1 - t0) + 21 * (t2 - t1)
-    clip_s = 2 * args.denoise_steps * t_fwd
-    return {"value": 1.0 / clip_s, "unit": "video-latents/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32: 1 CogVideoXBlock ({t1 - t0:.2f} s) + 1 PerceiverCrossAttention ({t2 - t1:.2f} s) at "
-                      f"{args.frames}f {args.height}x{args.width} (S={Sv + 226}), B=1; clip extrapolated as "
-                      f"{2 * args.denoise_steps} forwards x (42 blocks + 21 cross layers); embeds and VAE decode excluded"}
+    x = torch.randn(1, S, D, generator=g)
+    temb, ref = torch.randn(1, 512, generator=g), torch.randn(1, Sr, D, generator=g)
+    cos, sin = prepare_rotary(args.height, args.width, T, 2, 64)
+    pre = "transformer_blocks.0."
+    tick = time.perf_counter
+    # (a) block without attention: 2 x LayerNormZero, qkv + out projections, q/k LayerNorm + RoPE, FFN, gated residuals
+    t0 = tick()
+    n1, e1, gate, egate = dr.layer_norm_zero(p, sd, pre + "norm1.", x[:, 226:], x[:, :226], temb, 1e-5)
+    h = torch.cat([e1, n1], 1)
+    q, k, v = (p.linear(h, sd[pre + f"attn1.{n}.weight"], sd[pre + f"attn1.{n}.bias"]).view(1, S, 48, 64).transpose(1, 2)
+               for n in ("to_q", "to_k", "to_v"))
+    q = p.layer_norm(q, sd[pre + "attn1.norm_q.weight"], sd[pre + "attn1.norm_q.bias"], 1e-6)
+    k = p.layer_norm(k, sd[pre + "attn1.norm_k.weight"], sd[pre + "attn1.norm_k.bias"], 1e-6)
+    q = torch.cat([q[:, :, :226], dr.apply_rotary_emb(q[:, :, 226:], cos, sin)], 2)
+    k = torch.cat([k[:, :, :226], dr.apply_rotary_emb(k[:, :, 226:], cos, sin)], 2)
+    o = p.linear(v.transpose(1, 2).reshape(1, S, D), sd[pre + "attn1.to_out.0.weight"], sd[pre + "attn1.to_out.0.bias"])
+    x2 = x + torch.cat([egate.expand(1, 226, D), gate.expand(1, Sv, D)], 1) * o
+    n2, e2, gate, egate = dr.layer_norm_zero(p, sd, pre + "norm2.", x2[:, 226:], x2[:, :226], temb, 1e-5)
+    ff = dr.feed_forward(p, sd, pre + "ff.", torch.cat([e2, n2], 1))
+    x3 = x2 + torch.cat([egate.expand(1, 226, D), gate.expand(1, Sv, D)], 1) * ff
+    t_rows = tick() - t0
+    # (b) joint attention, `attn_heads` heads
+    t0 = tick()
+    dr.sdpa(p, q[:, :attn_heads], k[:, :attn_heads], v[:, :attn_heads], 0.125)
+    t_attn = (tick() - t0) * 48 / attn_heads
+    # (c) cross layer without attention
+    cp = "perceiver_cross_attention.0."
+    t0 = tick()
+    xn = p.layer_norm(ref, sd[cp + "norm1.weight"], sd[cp + "norm1.bias"], 1e-5)
+    ln = p.layer_norm(x3[:, 226:], sd[cp + "norm2.weight"], sd[cp + "norm2.bias"], 1e-5)
+    cq = p.linear(ln, sd[cp + "to_q.weight"]).view(1, Sv, 16, 128).transpose(1, 2) * 128 ** -0.25
+    ck, cv = (t.view(1, Sr, 16, 128).transpose(1, 2) for t in p.linear(xn, sd[cp + "to_kv.weight"]).chunk(2, -1))
+    ck = ck * 128 ** -0.25
+    p.linear(cq.transpose(1, 2).reshape(1, Sv, 2048), sd[cp + "to_out.weight"])
+    t_crows = tick() - t0
+    # (d) cross attention, `cross_heads` heads
+    t0 = tick()
+    dr.sdpa(p, cq[:, :cross_heads], ck[:, :cross_heads], cv[:, :cross_heads], 1.0)
+    t_cattn = (tick() - t0) * 16 / cross_heads
+    t_block, t_cross = t_rows + t_attn, t_crows + t_cattn
+    clip_s = 2 * args.denoise_steps * (42 * t_block + 21 * t_cross)
+    return {"value": 1.0 / clip_s, "unit": "video-latents/s", "cores": threads, "kind": "port",
+            "sample": f"oracle fp32, {args.frames}f {args.height}x{args.width} (S={S}), B=1: CogVideoXBlock = rows/GEMMs {t_rows:.2f} s + "
+                      f"attention {t_attn:.2f} s ({attn_heads}/48 heads timed, x{48 // attn_heads}); PerceiverCrossAttention = rows/GEMMs "
+                      f"{t_crows:.2f} s + attention {t_cattn:.2f} s ({cross_heads}/16 heads timed); clip extrapolated as "
+                      f"{2 * args.denoise_steps} forwards x (42 blocks + 21 cross layers); embeds and VAE decode excluded",
+            "extrapolated_clip_seconds": clip_s}
 
 
 def main():

@@ -30,7 +30,25 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* x, floa
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
     if (act) {
-        for (int64_t row = r0 + trow; row < r1; row += rows_per_it) {
+        int64_t row = r0 + trow;
+        // four independent 16-byte loads in flight per thread (the loop is latency bound otherwise)
+        for (; row + 3 * (int64_t)rows_per_it < r1; row += 4 * (int64_t)rows_per_it) {
+            u32x4 raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const u32x4*>(xn + (row + (int64_t)u * rows_per_it) * C + 8 * tch);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v[8];
+                unpack8(raw[u], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[e] - piv[e];
+                    s1[e] += d;
+                    s2[e] = __builtin_fmaf(d, d, s2[e]);
+                }
+            }
+        }
+        for (; row < r1; row += rows_per_it) {
             float v[8];
             unpack8(*reinterpret_cast<const u32x4*>(xn + row * C + 8 * tch), v);
 #pragma unroll
@@ -64,39 +82,51 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* x, floa
     }
 }
 
-__global__ void gn_finalize_kernel(const uint16_t* x, const float* partial, float* stats, int64_t S, int32_t C, int32_t G,
-                                   int32_t nsplit, int32_t N, float eps) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * G) return;
-    const int n = idx / G, g = idx - n * G;
-    const int cpg = C / G;
-    const double cnt = (double)S;
-    double tot = 0.0;
-    // pass 1: group mean
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        double s1 = 0.0;
-        for (int sp = 0; sp < nsplit; ++sp) s1 += partial[(((int64_t)n * nsplit + sp) * 2) * C + c];
-        const double K = bf16_bits_to_f32(x[(int64_t)n * S * C + c]);
-        tot += s1 + cnt * K;
-    }
-    const double mean = tot / (cnt * cpg);
-    // pass 2: sum (x - mean)^2 = sum (d - (mean - K))^2 with d = x - K
-    double m2 = 0.0;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int sp = 0; sp < nsplit; ++sp) {
+// one 256-thread block per (n, group): fp64 combine of the slabs and of the group's channels
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const uint16_t* x, const float* partial, float* stats, int64_t S, int32_t C,
+                                                          int32_t G, int32_t nsplit, float eps) {
+    __shared__ double r1[256], r2[256];
+    __shared__ double cs1[64], cs2[64];
+    const int n = blockIdx.x / G, g = blockIdx.x - n * G;
+    const int cpg = C / G;                      // <= 64 (host check)
+    const int tc = threadIdx.x % cpg, ts = threadIdx.x / cpg, nts = 256 / cpg;
+    double a1 = 0.0, a2 = 0.0;
+    if (ts < nts) {
+        const int c = g * cpg + tc;
+        for (int sp = ts; sp < nsplit; sp += nts) {
             const float* pp = partial + (((int64_t)n * nsplit + sp) * 2) * C;
-            s1 += pp[c];
-            s2 += pp[C + c];
+            a1 += pp[c];
+            a2 += pp[C + c];
         }
-        const double K = bf16_bits_to_f32(x[(int64_t)n * S * C + c]);
-        const double dm = mean - K;
-        m2 += s2 - 2.0 * dm * s1 + cnt * dm * dm;
     }
-    double var = m2 / (cnt * cpg);
-    if (var < 0.0) var = 0.0;
-    stats[2 * idx] = (float)mean;
-    stats[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    r1[threadIdx.x] = a1;
+    r2[threadIdx.x] = a2;
+    __syncthreads();
+    if (threadIdx.x < cpg) {
+        double b1 = 0.0, b2 = 0.0;
+        for (int j = 0; j < nts; ++j) {
+            b1 += r1[j * cpg + threadIdx.x];
+            b2 += r2[j * cpg + threadIdx.x];
+        }
+        cs1[threadIdx.x] = b1;
+        cs2[threadIdx.x] = b2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double cnt = (double)S;
+        double tot = 0.0;
+        for (int j = 0; j < cpg; ++j) tot += cs1[j] + cnt * (double)bf16_bits_to_f32(x[(int64_t)n * S * C + g * cpg + j]);
+        const double mean = tot / (cnt * cpg);
+        double m2 = 0.0;           // sum (x - mean)^2 = sum (d - (mean - K))^2 with d = x - K
+        for (int j = 0; j < cpg; ++j) {
+            const double dm = mean - (double)bf16_bits_to_f32(x[(int64_t)n * S * C + g * cpg + j]);
+            m2 += cs2[j] - 2.0 * dm * cs1[j] + cnt * dm * dm;
+        }
+        double var = m2 / (cnt * cpg);
+        if (var < 0.0) var = 0.0;
+        stats[2 * blockIdx.x] = (float)mean;
+        stats[2 * blockIdx.x + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 struct ApplyParams {
@@ -156,11 +186,11 @@ extern "C" int tcx_groupnorm_stats(const void* x, float* stats, float* partial, 
     TCX_CHECK(N > 0 && N < 65536 && spatial > 0 && C > 0 && G > 0 && C % G == 0 && C % 8 == 0 && C <= 2048, TCX_E_SHAPE,
               "tcx_groupnorm_stats: need C %% G == 0, C %% 8 == 0, C <= 2048 (C=%d G=%d)", C, G);
     TCX_CHECK(nsplit > 0 && nsplit <= 65535, TCX_E_SHAPE, "tcx_groupnorm_stats: bad nsplit %d", nsplit);
+    TCX_CHECK(C / G <= 64, TCX_E_SHAPE, "tcx_groupnorm_stats: at most 64 channels per group (C=%d G=%d)", C, G);
     TCX_CHECK(tcx_aligned16(x), TCX_E_ALIGN, "tcx_groupnorm_stats: x must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nsplit, N), dim3(256), 0, st, (const uint16_t*)x, partial, spatial, C, nsplit);
-    const int tot = N * G;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 63) / 64), dim3(64), 0, st, (const uint16_t*)x, partial, stats, spatial, C, G, nsplit, N, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(256), 0, st, (const uint16_t*)x, partial, stats, spatial, C, G, nsplit, eps);
     TCX_LAUNCH_RET();
 }
 

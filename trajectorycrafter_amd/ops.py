@@ -263,7 +263,7 @@ def groupnorm_stats(x: torch.Tensor, groups: int, eps: float) -> torch.Tensor:
     _need(x, "x")
     N, Cc = x.shape[0], x.shape[-1]
     S = x.numel() // (N * Cc)
-    nsplit = int(max(1, min(512, S // 256)))
+    nsplit = int(max(1, min(2048, S // 64)))
     stats = torch.empty((N, groups, 2), device=x.device, dtype=torch.float32)
     partial = torch.empty((N, nsplit, 2, Cc), device=x.device, dtype=torch.float32)
     check(_lib.load().tcx_groupnorm_stats(_p(x), _p(stats), _p(partial), N, S, Cc, groups, float(eps), nsplit, _stream()),
