@@ -137,7 +137,7 @@ int tcx_cfg_ddim_step(const void* u, const void* c, const void* x, void* out, in
                       float guidance, float alpha_t, float alpha_prev, int32_t pred_dtype, void* stream);
 
 /* ---- K11 / K12 / 1x1x1 convs: bf16 implicit-GEMM convolution, channels-last -------------------
- * y[n, t, oy, ox, co] = bias[co] + sum_{dt,dy,dx,ci} X(t + dt, (oy + dy - ph) , (ox + dx - pw), ci)
+ * y[n, t, oy, ox, co] = bias[co] + sum_{dt,dy,dx,ci} X(t + dt, oy*stride + dy - pad_h, ox*stride + dx - pad_w, ci)
  *                                                    * w[co, dt, dy, dx, ci]   (+ res[n,t,oy,ox,co])
  * where X is the logical input: rows t < kT-1 come from `cache` (the previous chunk's last kT-1
  * input frames, or the first frame replicated when cache is null), the rest from `x`; spatial
@@ -145,7 +145,9 @@ int tcx_cfg_ddim_step(const void* u, const void* c, const void* x, void* out, in
  * `x` (never materialised); `t_map` (int32 [T_out], device, or null = identity) maps an output
  * frame to the source frame of `x` (the temporal part of CogVideoXUpsample3D).
  * Layouts: x [N, T_in, H_in, W_in, Cin] bf16; w [Cout, kT, kH, kW, Cin] bf16 (pre-permuted by the
- * host from the reference's [Cout, Cin, kT, kH, kW]); y [N, T_out, H, W, Cout] bf16.
+ * host from the reference's [Cout, Cin, kT, kH, kW]); y [N, T_out, H_out, W_out, Cout] bf16.
+ * stride in {1, 2} (spatial; 2 = the encoder's CogVideoXDownsample3D conv with its (0,1,0,1) padding:
+ * pad_h = pad_w = 0 and the extra bottom / right zero row comes from the range check).
  * Replaces: CogVideoXCausalConv3d.forward + CogVideoXSafeConv3d (models/autoencoder_magvit.py:
  *   41-73,136-163), the interpolate + Conv2d of diffusers CogVideoXUpsample3D (built :620-630),
  *   the 1x1x1 conv_shortcut (:312-318,351-352) and the residual add (:354).
@@ -154,8 +156,15 @@ int tcx_cfg_ddim_step(const void* u, const void* c, const void* x, void* out, in
 int tcx_conv3d_cl(const void* x, const void* cache, const void* w, const void* bias, const void* res,
                   void* y,
                   int32_t N, int32_t T_in, int32_t H_in, int32_t W_in, int32_t Cin, int32_t Cout,
-                  int32_t kT, int32_t kH, int32_t kW, int32_t T_out, int32_t ups, const int32_t* t_map,
+                  int32_t kT, int32_t kH, int32_t kW, int32_t T_out, int32_t ups, int32_t stride,
+                  int32_t pad_h, int32_t pad_w, int32_t H_out, int32_t W_out, const int32_t* t_map,
                   void* stream);
+
+/* ---- temporal average pool of diffusers CogVideoXDownsample3D(compress_time) -------------------
+ * x [N, T, S, C] channels-last bf16 (S = H*W) -> y [N, T', S, C]: T even: pairs averaged (T' = T/2);
+ * T odd: frame 0 kept, frames 1.. averaged pairwise (T' = 1 + (T-1)/2).  fp32 mean, one rounding.
+ * Replaces: the avg_pool1d branch the encoder's down blocks run (built models/autoencoder_magvit.py:423-435). */
+int tcx_avgpool_t(const void* x, void* y, int32_t N, int32_t T, int64_t S, int32_t C, void* stream);
 
 /* ---- K13: GroupNorm statistics + fused GroupNorm * SpatialNorm modulate + SiLU ----------------
  * stats: per (n, group) mean / rstd over (T, H, W, C/G) of channels-last x [N, spatial, C] bf16.

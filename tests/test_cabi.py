@@ -40,7 +40,7 @@ def test_argument_validation_without_gpu():
     assert rc == -3
     rc = lib.tcx_layernorm_modulate(p, p, 1, 4, 12, 48, 48, None, None, None, None, None, None, 0, 0, 1e-5, None)
     assert rc == -1                       # C % 8 != 0
-    rc = lib.tcx_conv3d_cl(p, None, p, None, None, p, 1, 2, 4, 4, 12, 8, 3, 3, 3, 2, 0, None, None)
+    rc = lib.tcx_conv3d_cl(p, None, p, None, None, p, 1, 2, 4, 4, 12, 8, 3, 3, 3, 2, 0, 1, 1, 1, 4, 4, None, None)
     assert rc == -1                       # Cin % 8 != 0
 
 

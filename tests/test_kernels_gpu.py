@@ -393,3 +393,21 @@ def test_layout_kernels(ops):
     ref = (from_cl(cl).float() / 2 + 0.5).to(BF).float().clamp(0, 1)
     assert torch.equal(out[:, :, 5:].cpu(), ref)
     assert float(out[:, :, :5].abs().max()) == 0
+
+
+@pytest.mark.parametrize("T,compress", [(5, True), (4, True), (3, False), (1, True)])
+def test_downsample_conv_and_avgpool(ops, T, compress):
+    """diffusers CogVideoXDownsample3D: temporal avg-pool + stride-2 conv on the (0,1,0,1)-padded frame."""
+    g = torch.Generator().manual_seed(T + 40)
+    C, H, W = 32, 10, 12
+    p = Prec("bf16")
+    x = bf(torch.randn(1, C, T, H, W, generator=g))
+    w = bf(torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C))
+    b = bf(torch.randn(C, generator=g) * 0.1)
+    ref = dr.downsample3d(p, {"conv.weight": w.float(), "conv.bias": b.float()}, "", x.float(), compress)
+    xcl = dev(to_cl(x))
+    if compress and T > 1:
+        xcl = ops.avgpool_t(xcl)
+    y = ops.conv3d_cl(xcl, dev(w.permute(0, 2, 3, 1).reshape(C, 1, 3, 3, C).contiguous()), dev(b), stride=2, pad=(0, 0),
+                      out_hw=(H // 2, W // 2))
+    assert_bf16_close(from_cl(y), ref, atol=2e-3)

@@ -147,3 +147,30 @@ def test_vae_decode_tiny(golden, gpu):
     # fused frames epilogue == (x/2+.5).clamp(0,1).float()
     fr = vae.decode_to_frames(z.to(gpu))
     assert torch.equal(fr, (dec / 2 + 0.5).clamp(0, 1).float())
+
+
+def test_vae_encode_tiny(golden, gpu):
+    """HIP VAE encoder (stride-2 conv gather, temporal avg-pool, GroupNorm+SiLU, 4-frame chunks with conv cache)."""
+    from trajectorycrafter_amd.models.autoencoder_magvit import AutoencoderKLCogVideoX
+    t, meta = golden("vae_tiny.safetensors")
+    cfg = ast.literal_eval(meta["config"])
+    sd = _weights(t)
+    vae = AutoencoderKLCogVideoX(**cfg)
+    vae.load_state_dict(sd, strict=True)
+    vae = vae.to(gpu, BF).eval()
+    sdf = {k: v.float() for k, v in sd.items()}
+    video = t["video"].to(BF)
+    post = vae.encode(video.to(gpu)).latent_dist
+    ref = ovae.vae_encode(sdf, cfg, video.float(), prec="bf16")
+    assert post.mean.shape == t["enc_mean"].shape == (1, 16, 3, 4, 6)
+    _check_deep(post.mean, ref.mean, t["enc_mean"], "vae encode mean (9 frames, 2 chunks)")
+    _check_deep(post.logvar, ref.logvar, t["enc_logvar"], "vae encode logvar")
+    assert torch.equal(vae.encode(video.to(gpu))[0].mode(), post.mean)       # re-entrant, tuple access like the reference
+    g = torch.Generator(device="cuda").manual_seed(1)
+    smp = post.sample(g)
+    assert smp.shape == post.mean.shape and torch.isfinite(smp.float()).all()
+    # single frame path (:1193-1197)
+    p1 = vae.encode(video[:, :, :1].to(gpu)).latent_dist
+    r1 = ovae.vae_encode(sdf, cfg, video[:, :, :1].float(), prec="bf16")
+    e1 = ovae.vae_encode(sdf, cfg, video[:, :, :1].float(), prec="fp32")
+    _check_deep(p1.mean, r1.mean, e1.mean, "vae encode single frame")

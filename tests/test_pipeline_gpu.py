@@ -81,6 +81,38 @@ def test_pipeline_error_surface(setup):
         s["pipe"](prompt=None, height=32, width=48, num_frames=9)
     with pytest.raises(ValueError, match="same shape"):
         s["pipe"](height=32, width=48, num_frames=9, **dict(base, negative_prompt_embeds=pe[:, :5]))
-    with pytest.raises(NotImplementedError, match="encoder"):
+    with pytest.raises(ValueError, match="required to build the conditioning"):
         s["pipe"](prompt=None, prompt_embeds=pe, negative_prompt_embeds=pe, height=32, width=48, num_frames=9,
-                  video=tp["video"], mask_video=tp["mask_video"], reference=tp["reference"], num_inference_steps=1)
+                  num_inference_steps=1)
+
+
+def test_conditioning_from_pixels_matches_oracle(setup):
+    """reference :862-897, :927-1028 through the HIP VAE encoder: masked-video latents + resized mask (deterministic:
+    `.mode()`), and the reference-frame posterior (mean / std; its `.sample()` draws from the device RNG)."""
+    s, tp = setup, setup["tp"]
+    pipe, dev = s["pipe"], s["dev"]
+    inpaint, ref_lat = pipe._build_conditioning(tp["video"], tp["mask_video"], tp["reference"], 32, 48, True, BF, dev)
+    assert inpaint.shape == (1, 3, 17, 4, 6) and ref_lat.shape == (1, 2, 16, 4, 6)
+    exact_inp, _ = opl.build_conditioning(s["wv"], s["vae_cfg"], tp["video"], tp["mask_video"], tp["reference"], 32, 48, "fp32", do_cfg=False)
+    contract_inp, _ = opl.build_conditioning(s["wv"], s["vae_cfg"], tp["video"], tp["mask_video"], tp["reference"], 32, 48, "bf16", do_cfg=False)
+    _check_deep(inpaint, contract_inp, exact_inp, "inpaint latents from pixels (VAE encode of the masked render)")
+    # mask channel is exact up to one rounding (pure resize * scaling factor)
+    assert float((inpaint[:, :, 0].float().cpu() - exact_inp[:, :, 0]).abs().max()) <= 2.0 ** -7
+    # all-valid mask (== 255 everywhere) -> zero inpaint latents (:928-948)
+    z, _ = pipe._build_conditioning(tp["video"], torch.full_like(tp["mask_video"], 255.0), tp["reference"], 32, 48, True, BF, dev)
+    assert float(z.abs().max()) == 0.0
+
+
+def test_pipeline_from_pixels_runs_end_to_end(setup):
+    s, tp = setup, setup["tp"]
+    kw = dict(prompt=None, height=32, width=48, num_frames=9, num_inference_steps=2, guidance_scale=6.0,
+              prompt_embeds=tp["prompt_embeds"].to(BF), negative_prompt_embeds=tp["negative_prompt_embeds"].to(BF),
+              latents=tp["latents0"].to(BF), video=tp["video"], mask_video=tp["mask_video"], reference=tp["reference"])
+    torch.manual_seed(5)
+    a = s["pipe"](**kw).videos
+    torch.manual_seed(5)
+    b = s["pipe"](**kw).videos
+    assert a.shape == (1, 3, 9, 32, 48) and torch.isfinite(a).all() and float(a.min()) >= 0 and float(a.max()) <= 1
+    assert torch.equal(a, b)                       # same device-RNG seed -> same reference-latent sample -> same frames
+    # (no comparison with the fixture frames here: the reference-frame posterior is *sampled* from the device RNG,
+    #  reference :886; the deterministic parts are pinned in test_conditioning_from_pixels_matches_oracle)

@@ -21,7 +21,8 @@ struct ConvParams {
     const uint16_t *x, *cache, *w, *bias, *res;
     uint16_t* y;
     const int32_t* t_map;
-    int32_t N, T_in, H_in, W_in, Cin, Cout, kT, kH, kW, T_out, H, W, ups;
+    int32_t N, T_in, H_in, W_in, Cin, Cout, kT, kH, kW, T_out, H, W, ups;   // H, W: output grid
+    int32_t LH, LW, stride, pad_h, pad_w;                                      // logical input grid (after the x2 upsample)
     int32_t Ktot;       // kT*kH*kW*Cin
     int64_t M;          // N*T_out*H*W
     uint32_t ntn, nwg;  // N tiles (co), total workgroups
@@ -61,7 +62,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         xn[i] = (int)(fr / p.T_out);
         xt[i] = (int)(fr - (int64_t)xn[i] * p.T_out);
     }
-    const int ph = p.kH >> 1, pw = p.kW >> 1;
     const int64_t frame_elems = (int64_t)p.H_in * p.W_in * p.Cin;
 
     u32x4 wreg[2], xreg[2];
@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         for (int i = 0; i < 2; ++i) {
             xreg[i] = u32x4{0, 0, 0, 0};
             if (!kvalid || !xvalid[i]) continue;
-            const int iy = xoy[i] + dy - ph, ix = xox[i] + dx - pw;
-            if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) continue;
+            const int iy = xoy[i] * p.stride + dy - p.pad_h, ix = xox[i] * p.stride + dx - p.pad_w;
+            if (iy < 0 || iy >= p.LH || ix < 0 || ix >= p.LW) continue;
             const int li = xt[i] + dt;                       // logical input frame (cache frames first)
             const uint16_t* fb;
             if (li < p.kT - 1) {
@@ -190,13 +190,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
 extern "C" int tcx_conv3d_cl(const void* x, const void* cache, const void* w, const void* bias, const void* res, void* y,
                              int32_t N, int32_t T_in, int32_t H_in, int32_t W_in, int32_t Cin, int32_t Cout,
-                             int32_t kT, int32_t kH, int32_t kW, int32_t T_out, int32_t ups, const int32_t* t_map,
+                             int32_t kT, int32_t kH, int32_t kW, int32_t T_out, int32_t ups, int32_t stride,
+                             int32_t pad_h, int32_t pad_w, int32_t H_out, int32_t W_out, const int32_t* t_map,
                              void* stream) {
     TCX_CHECK(x && w && y, TCX_E_NULL, "tcx_conv3d_cl: null x/w/y");
     TCX_CHECK(N > 0 && T_in > 0 && H_in > 0 && W_in > 0 && Cin > 0 && Cout > 0 && T_out > 0, TCX_E_SHAPE, "tcx_conv3d_cl: empty shape");
     TCX_CHECK(Cin % 8 == 0, TCX_E_SHAPE, "tcx_conv3d_cl: Cin (%d) must be a multiple of 8 (pad channels on the host)", Cin);
     TCX_CHECK(kT >= 1 && kT <= 3 && (kH == 1 || kH == 3) && (kW == 1 || kW == 3), TCX_E_SHAPE, "tcx_conv3d_cl: kernel %dx%dx%d unsupported", kT, kH, kW);
     TCX_CHECK(ups == 0 || ups == 1, TCX_E_SHAPE, "tcx_conv3d_cl: ups must be 0 or 1");
+    TCX_CHECK(stride == 1 || stride == 2, TCX_E_SHAPE, "tcx_conv3d_cl: stride must be 1 or 2");
+    TCX_CHECK(pad_h >= 0 && pad_h < kH && pad_w >= 0 && pad_w < kW && H_out > 0 && W_out > 0, TCX_E_SHAPE, "tcx_conv3d_cl: bad padding / output size");
+    TCX_CHECK((H_out - 1) * stride - pad_h < (H_in << ups) && (W_out - 1) * stride - pad_w < (W_in << ups), TCX_E_SHAPE,
+              "tcx_conv3d_cl: output grid %dx%d reads past the input", H_out, W_out);
     TCX_CHECK(t_map != nullptr || T_out == T_in, TCX_E_SHAPE, "tcx_conv3d_cl: T_out (%d) != T_in (%d) needs a t_map", T_out, T_in);
     TCX_CHECK(!(kT > 1 && t_map), TCX_E_SHAPE, "tcx_conv3d_cl: t_map is only supported with kT == 1");
     TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(cache) && tcx_aligned16(w) && tcx_aligned16(y) && tcx_aligned16(res) &&
@@ -206,7 +211,8 @@ extern "C" int tcx_conv3d_cl(const void* x, const void* cache, const void* w, co
     p.x = (const uint16_t*)x; p.cache = (const uint16_t*)cache; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias;
     p.res = (const uint16_t*)res; p.y = (uint16_t*)y; p.t_map = t_map;
     p.N = N; p.T_in = T_in; p.H_in = H_in; p.W_in = W_in; p.Cin = Cin; p.Cout = Cout; p.kT = kT; p.kH = kH; p.kW = kW;
-    p.T_out = T_out; p.H = H_in << ups; p.W = W_in << ups; p.ups = ups;
+    p.T_out = T_out; p.H = H_out; p.W = W_out; p.ups = ups;
+    p.LH = H_in << ups; p.LW = W_in << ups; p.stride = stride; p.pad_h = pad_h; p.pad_w = pad_w;
     p.Ktot = kT * kH * kW * Cin;
     p.M = (int64_t)N * T_out * p.H * p.W;
     p.ntn = (uint32_t)((Cout + BN - 1) / BN);

@@ -183,7 +183,43 @@ __global__ __launch_bounds__(256) void cl_to_frames_kernel(const uint16_t* x, fl
     }
 }
 
+// temporal average pool (pairs; odd T keeps frame 0): x [N,T,S,C] -> y [N,T',S,C]
+__global__ __launch_bounds__(256) void avgpool_t_kernel(const uint16_t* x, uint16_t* y, int32_t T, int32_t To, int64_t SC8) {
+    const int n = blockIdx.y;
+    const int odd = T & 1;
+    const int64_t total = (int64_t)To * SC8;
+    const uint16_t* xn = x + (int64_t)n * T * SC8 * 8;
+    uint16_t* yn = y + (int64_t)n * To * SC8 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int to = (int)(i / SC8);
+        const int64_t r = i - (int64_t)to * SC8;
+        float a[8], b[8], o[8];
+        if (odd && to == 0) {
+            *reinterpret_cast<u32x4*>(yn + i * 8) = *reinterpret_cast<const u32x4*>(xn + r * 8);
+            continue;
+        }
+        const int t0 = odd ? 1 + 2 * (to - 1) : 2 * to;
+        unpack8(*reinterpret_cast<const u32x4*>(xn + ((int64_t)t0 * SC8 + r) * 8), a);
+        unpack8(*reinterpret_cast<const u32x4*>(xn + ((int64_t)(t0 + 1) * SC8 + r) * 8), b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (a[e] + b[e]) * 0.5f;
+        *reinterpret_cast<u32x4*>(yn + i * 8) = pack8(o);
+    }
+}
+
 }  // namespace
+
+extern "C" int tcx_avgpool_t(const void* x, void* y, int32_t N, int32_t T, int64_t S, int32_t C, void* stream) {
+    TCX_CHECK(x && y, TCX_E_NULL, "tcx_avgpool_t: null pointer");
+    TCX_CHECK(N > 0 && N < 65536 && T > 0 && S > 0 && C > 0 && C % 8 == 0, TCX_E_SHAPE, "tcx_avgpool_t: bad shape (C %% 8 == 0 required)");
+    TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(y), TCX_E_ALIGN, "tcx_avgpool_t: pointers must be 16-byte aligned");
+    const int To = (T & 1) ? 1 + (T - 1) / 2 : T / 2;
+    TCX_CHECK(To > 0, TCX_E_SHAPE, "tcx_avgpool_t: T must be >= 2 or odd");
+    const int64_t SC8 = S * (C / 8);
+    hipLaunchKernelGGL(avgpool_t_kernel, dim3(grid_for((int64_t)To * SC8), N), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                       (uint16_t*)y, T, To, SC8);
+    TCX_LAUNCH_RET();
+}
 
 extern "C" int tcx_gated_residual(void* x, const void* y, int32_t B, int32_t rows, int32_t C, int64_t xsb, int64_t ysb,
                                   const void* gate_v, const void* gate_t, int64_t gsb, int32_t text_len, void* stream) {

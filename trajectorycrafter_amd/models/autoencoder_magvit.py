@@ -198,13 +198,22 @@ class CogVideoXUpsample3D(nn.Module):
 
 
 class CogVideoXDownsample3D(nn.Module):
-    """diffusers CogVideoXDownsample3D (encoder; parameters kept so checkpoints load)."""
+    """diffusers CogVideoXDownsample3D: temporal avg-pool (compress_time) then per-frame Conv2d 3x3 stride 2 on the
+    (0,1,0,1)-padded frame — the padding is the conv gather's range check, never a tensor."""
 
     def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 2, padding: int = 0,
                  compress_time: bool = False):
         super().__init__()
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding)
         self.compress_time = compress_time
+        self._wcl = _PermutedWeight()
+
+    def forward_cl(self, x: torch.Tensor) -> torch.Tensor:
+        if self.compress_time and x.shape[1] > 1:
+            x = ops.avgpool_t(x)
+        N, T, H, W, C = x.shape
+        return ops.conv3d_cl(x, self._wcl.get(self.conv.weight), self.conv.bias, stride=2, pad=(0, 0),
+                             out_hw=((H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1))
 
 
 class CogVideoXDownBlock3D(nn.Module):
@@ -221,6 +230,14 @@ class CogVideoXDownBlock3D(nn.Module):
         if add_downsample:
             self.downsamplers = nn.ModuleList([CogVideoXDownsample3D(out_channels, out_channels, padding=downsample_padding,
                                                                      compress_time=compress_time)])
+
+    def forward_cl(self, x):
+        for r in self.resnets:
+            x = r.forward_cl(x, None)
+        if self.downsamplers is not None:
+            for d in self.downsamplers:
+                x = d.forward_cl(x)
+        return x
 
 
 class CogVideoXMidBlock3D(nn.Module):
@@ -266,7 +283,7 @@ class CogVideoXUpBlock3D(nn.Module):
 
 
 class CogVideoXEncoder3D(nn.Module):
-    """reference :663-800 (parameters; the HIP encode path is the next hot-path row)."""
+    """reference :663-800."""
 
     def __init__(self, in_channels: int = 3, out_channels: int = 16,
                  down_block_types: Tuple[str, ...] = ("CogVideoXDownBlock3D",) * 4,
@@ -290,6 +307,15 @@ class CogVideoXEncoder3D(nn.Module):
         self.norm_out = nn.GroupNorm(norm_num_groups, block_out_channels[-1], eps=1e-6)
         self.conv_act = nn.SiLU()
         self.conv_out = CogVideoXCausalConv3d(block_out_channels[-1], 2 * out_channels, kernel_size=3, pad_mode=pad_mode)
+
+    def forward_cl(self, x: torch.Tensor) -> torch.Tensor:
+        """x channels-last [N,T,H,W,3(+pad)] -> moments [N,T',H/8,W/8,32] (reference :773-800)."""
+        h = self.conv_in.forward_cl(x)
+        for blk in self.down_blocks:
+            h = blk.forward_cl(h)
+        h = self.mid_block.forward_cl(h, None)
+        h = _groupnorm_silu(self.norm_out, h)
+        return self.conv_out.forward_cl(h)
 
 
 class CogVideoXDecoder3D(nn.Module):
@@ -333,6 +359,33 @@ class CogVideoXDecoder3D(nn.Module):
 @dataclass
 class DecoderOutput:
     sample: torch.Tensor
+
+
+class DiagonalGaussianDistribution:
+    """diffusers DiagonalGaussianDistribution (used at reference :1197,1212)."""
+
+    def __init__(self, parameters: torch.Tensor):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+
+    def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        dev = generator.device if generator is not None else self.mean.device
+        noise = torch.randn(self.mean.shape, generator=generator, device=dev, dtype=self.mean.dtype).to(self.mean.device)
+        return self.mean + self.std * noise
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
+
+
+@dataclass
+class AutoencoderKLOutput:
+    latent_dist: DiagonalGaussianDistribution
+
+    def __getitem__(self, i):
+        return (self.latent_dist,)[i]
 
 
 class AutoencoderKLCogVideoX(ModelMixin, ConfigMixin):
@@ -442,6 +495,27 @@ class AutoencoderKLCogVideoX(ModelMixin, ConfigMixin):
         self._decode_cl(z, frames, scale)
         return frames
 
+    @torch.no_grad()
     def encode(self, x: torch.Tensor, return_dict: bool = True):
-        raise NotImplementedError("the HIP VAE encoder is the next hot-path row (SURVEY §8f-f1); pass pre-encoded "
-                                  "conditioning latents to the pipeline (`inpaint_latents=` / `ref_latents=`)")
+        """reference :1176-1215: x [N,3,F,H,W] bf16 in [-1,1] -> posterior over [N,16,T,H/8,W/8] (4-frame chunks
+        with the remainder folded into the first, conv caches carried across chunks)."""
+        if not x.is_cuda or x.dtype != BF16 or self.dtype != BF16:
+            raise TcxError(f"AutoencoderKLCogVideoX.encode: needs bf16 pixels and weights on the GPU "
+                           f"(got {x.dtype} on {x.device}, weights {self.dtype}); no CPU fallback")
+        N, C, Fr, H, W = x.shape
+        if H % 8 or W % 8:
+            raise ValueError(f"encode: height and width must be divisible by 8, got {H}x{W}")
+        xcl = _pad_channels(ops.ncthw_to_cl(x))
+        self._clear_fake_context_parallel_cache()
+        if Fr == 1:
+            bounds = [(0, 1)]
+        else:
+            fbs, rem = 4, Fr % 4
+            bounds = [(fbs * i + (0 if i == 0 else rem), fbs * (i + 1) + rem) for i in range(Fr // fbs)]
+        hs = [self.encoder.forward_cl(xcl[:, s:e].contiguous()) for s, e in bounds]
+        self._clear_fake_context_parallel_cache()
+        moments = torch.cat(hs, dim=1).permute(0, 4, 1, 2, 3).contiguous()          # -> [N,32,T,h,w]
+        posterior = DiagonalGaussianDistribution(moments)
+        if not return_dict:
+            return (posterior,)
+        return AutoencoderKLOutput(latent_dist=posterior)

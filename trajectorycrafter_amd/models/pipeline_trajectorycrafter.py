@@ -5,9 +5,9 @@ the HIP-backed `CrossTransformer3DModel`, the fused CFG + DDIM kernel and the HI
 Nothing on this path syncs with the host inside the loop (timesteps / alphas are host scalars).
 
 Two extension kwargs (ignored by reference callers): `inpaint_latents=` and `ref_latents=` take
-pre-encoded conditioning (what :875-897 / :927-1028 build through `vae.encode`), because the HIP VAE
-*encoder* is the next hot-path row; without them and without an encoder the call
-raises instead of silently running torch.
+pre-encoded conditioning (what :875-897 / :927-1028 build through `vae.encode`) so that benchmarks and
+data-parallel runs can skip the pixel-space stage; without them the conditioning is built from
+`video` / `mask_video` / `reference` with the HIP VAE encoder exactly as the reference does.
 """
 from __future__ import annotations
 
@@ -238,12 +238,46 @@ class TrajCrafter_Pipeline:
         z = latents.permute(0, 2, 1, 3, 4)
         return self.vae.decode_to_frames(z, scale=1.0 / self.vae.config.scaling_factor)
 
+    @staticmethod
+    def _preprocess(x: torch.Tensor, height: int, width: int, do_normalize: bool = True, do_binarize: bool = False):
+        """diffusers VaeImageProcessor.preprocess for [B,C,F,H,W] tensors (:864-870,876-879,952-960)."""
+        b, c, f = x.shape[:3]
+        y = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, *x.shape[3:]).float()
+        if y.shape[-2:] != (height, width):
+            y = F.interpolate(y, size=(height, width))
+        if do_normalize and float(y.min()) >= 0:
+            y = 2.0 * y - 1.0
+        if do_binarize:
+            y = (y >= 0.5).to(y.dtype)
+        return y.reshape(b, f, c, height, width).permute(0, 2, 1, 3, 4)
+
     def _build_conditioning(self, video, mask_video, reference, height, width, do_cfg, dtype, device):
-        """reference :862-897, :927-1028 — needs the VAE encoder."""
-        raise NotImplementedError(
-            "building inpaint / reference latents from pixels needs the HIP VAE encoder (next hot-path row, SURVEY §8f-f1); "
-            "pass `inpaint_latents=` [2B,T,17,h,w] and `ref_latents=` [2B,Tr,16,h,w] (e.g. produced by the reference's "
-            "conditioning stage) — see INTEGRATION.md")
+        """reference :862-897 and :927-1028: pixels -> (inpaint_latents [B,T,17,h,w], ref_latents [B,Tr,16,h,w]) through
+        the HIP VAE encoder.  The elementwise preparation (normalise, binarise, trilinear mask resize) is
+        conditioning I/O on small tensors and stays in torch."""
+        if video is None or reference is None:
+            raise ValueError("`video` and `reference` are required to build the conditioning (or pass `inpaint_latents=` / "
+                             "`ref_latents=` directly)")
+        sf = self.vae.config.scaling_factor
+        init_video = self._preprocess(video.to(device), height, width)
+        ref_video = self._preprocess(reference.to(device), height, width)
+        ref_lat = self.vae.encode(ref_video.to(dtype))[0].sample() * sf                              # :885-889 (global RNG)
+        ref_lat = ref_lat.to(dtype).permute(0, 2, 1, 3, 4)
+        B, _, Fv = video.shape[:3]
+        T = (Fv - 1) // self.vae_scale_factor_temporal + 1
+        h, w = height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial
+        if mask_video is None or bool((mask_video == 255).all()):                                      # :928-948
+            mask_lat = torch.zeros(B, T, 1, h, w, device=device, dtype=dtype)
+            mv_lat = torch.zeros(B, T, self.vae.config.latent_channels, h, w, device=device, dtype=dtype)
+        else:
+            mask_cond = self._preprocess(mask_video.to(device), height, width, do_normalize=False, do_binarize=True)
+            tile = mask_cond.repeat(1, 3, 1, 1, 1)
+            masked_video = init_video * (tile < 0.5) + torch.ones_like(init_video) * (tile > 0.5) * -1   # :969-974
+            mv = (self.vae.encode(masked_video.to(dtype))[0].mode() * sf).to(dtype)                    # :498-502
+            mask_lat = (resize_mask(1 - mask_cond, mv) * sf).to(dtype).permute(0, 2, 1, 3, 4)          # :991-996
+            mv_lat = mv.permute(0, 2, 1, 3, 4)
+        inpaint = torch.cat([mask_lat, mv_lat], dim=2).contiguous()                                    # :1026-1028
+        return inpaint, ref_lat.contiguous()
 
     @torch.no_grad()
     def __call__(

@@ -222,8 +222,12 @@ def cfg_ddim_step(uncond: torch.Tensor, cond: Optional[torch.Tensor], x: torch.T
 
 # ----------------------------------------------------------------------------- VAE (channels-last [N,T,H,W,C])
 def conv3d_cl(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], cache: Optional[torch.Tensor] = None,
-              res: Optional[torch.Tensor] = None, ups: int = 0, t_map: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x [N,T,H,W,Cin], w [Cout,kT,kH,kW,Cin] (pre-permuted), cache [N,kT-1,H,W,Cin] -> y [N,T',H',W',Cout]."""
+              res: Optional[torch.Tensor] = None, ups: int = 0, t_map: Optional[torch.Tensor] = None,
+              stride: int = 1, pad: Optional[Tuple[int, int]] = None, out_hw: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """x [N,T,H,W,Cin], w [Cout,kT,kH,kW,Cin] (pre-permuted), cache [N,kT-1,H,W,Cin] -> y [N,T',H',W',Cout].
+
+    Default: "same" convolution (pad = k // 2 on both sides).  `stride=2, pad=(0, 0), out_hw=(H//2, W//2)` is the
+    encoder's downsample conv (zero row / column appended at the bottom / right by the range check)."""
     _need(x, "x"); _need(w, "w")
     if not (x.is_contiguous() and w.is_contiguous()):
         raise TcxError("conv3d_cl: x and w must be contiguous")
@@ -238,13 +242,27 @@ def conv3d_cl(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], ca
             raise TcxError(f"conv3d_cl: cache must be contiguous [N,{kT - 1},H,W,Cin], got {tuple(cache.shape)}")
     if t_map is not None and (t_map.dtype != torch.int32 or not t_map.is_cuda):
         raise TcxError("conv3d_cl: t_map must be a GPU int32 tensor")
-    y = torch.empty((N, T_out, H << ups, W << ups, Cout), device=x.device, dtype=BF16)
+    ph, pw = (kH // 2, kW // 2) if pad is None else pad
+    Ho, Wo = ((H << ups), (W << ups)) if out_hw is None else out_hw
+    y = torch.empty((N, T_out, Ho, Wo, Cout), device=x.device, dtype=BF16)
     if res is not None:
         _need(res, "res")
         if res.shape != y.shape or not res.is_contiguous():
             raise TcxError(f"conv3d_cl: residual must be contiguous {tuple(y.shape)}, got {tuple(res.shape)}")
     check(_lib.load().tcx_conv3d_cl(_p(x), _p(cache), _p(w), _p(bias), _p(res), _p(y), N, T, H, W, Cin, Cout, kT, kH, kW,
-                                    T_out, ups, _p(t_map), _stream()), "tcx_conv3d_cl")
+                                    T_out, ups, stride, ph, pw, Ho, Wo, _p(t_map), _stream()), "tcx_conv3d_cl")
+    return y
+
+
+def avgpool_t(x: torch.Tensor) -> torch.Tensor:
+    """Temporal average pool of CogVideoXDownsample3D(compress_time): x [N,T,H,W,C] -> [N,T',H,W,C]."""
+    _need(x, "x")
+    if not x.is_contiguous():
+        raise TcxError("avgpool_t: x must be contiguous")
+    N, T, H, W, Cc = x.shape
+    To = T // 2 if T % 2 == 0 else 1 + (T - 1) // 2
+    y = torch.empty((N, To, H, W, Cc), device=x.device, dtype=BF16)
+    check(_lib.load().tcx_avgpool_t(_p(x), _p(y), N, T, H * W, Cc, _stream()), "tcx_avgpool_t")
     return y
 
 
