@@ -1,0 +1,135 @@
+"""Host-side logic of the product package against the oracle (CPU only, no kernels launched)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import diffusers_restated as dr
+from oracle import pipeline as opl
+from trajectorycrafter_amd import init_weights as iw
+from trajectorycrafter_amd.models.autoencoder_magvit import AutoencoderKLCogVideoX, upsample_t_map, zq_t_map
+from trajectorycrafter_amd.models.crosstransformer3d import CrossTransformer3DModel, Timesteps
+from trajectorycrafter_amd.models.pipeline_trajectorycrafter import (TrajCrafter_Pipeline, get_3d_rotary_pos_embed,
+                                                                    get_resize_crop_region_for_grid, resize_mask)
+from trajectorycrafter_amd.scheduler import DDIMScheduler
+
+
+def test_scheduler_matches_oracle_tables():
+    a, b = DDIMScheduler(), dr.DDIMScheduler()
+    torch.testing.assert_close(a.alphas_cumprod, b.alphas_cumprod, rtol=0, atol=0)
+    for n in (1, 2, 25, 50):
+        a.set_timesteps(n), b.set_timesteps(n)
+        assert a.timesteps.tolist() == b.timesteps.tolist()
+        for t in a.timesteps.tolist():
+            at, ap = a.coeffs(t)
+            bt, bp = b.coeffs(t)
+            assert at == float(bt) and ap == float(bp)
+    assert a.init_noise_sigma == 1.0 and a.order == 1 and a.config.prediction_type == "v_prediction"
+    with pytest.raises(ValueError):
+        DDIMScheduler(prediction_type="epsilon")
+    with pytest.raises(ValueError):
+        a.set_timesteps(5000)
+
+
+def test_scheduler_from_pretrained(tmp_path):
+    d = tmp_path / "scheduler"
+    d.mkdir()
+    (d / "scheduler_config.json").write_text(json.dumps({"_class_name": "DDIMScheduler", "num_train_timesteps": 1000,
+                                                         "beta_start": 0.00085, "beta_end": 0.012, "timestep_spacing": "trailing",
+                                                         "rescale_betas_zero_snr": True, "snr_shift_scale": 1.0}))
+    s = DDIMScheduler.from_pretrained(str(tmp_path), subfolder="scheduler")
+    s.set_timesteps(50)
+    assert s.timesteps[0] == 999
+
+
+@pytest.mark.parametrize("hw", [(480, 720), (384, 672), (256, 256)])
+def test_rope_tables_match_oracle(hw):
+    H, W = hw
+    cos, sin = opl.prepare_rotary(H, W, 13, 2, 64)
+    gh, gw = H // 16, W // 16
+    crops = get_resize_crop_region_for_grid((gh, gw), 45, 30)
+    c2, s2 = get_3d_rotary_pos_embed(64, crops, (gh, gw), 13)
+    assert torch.equal(cos, c2) and torch.equal(sin, s2)
+
+
+def test_timesteps_module_matches_oracle():
+    t = torch.tensor([999, 19, 0])
+    torch.testing.assert_close(Timesteps(3072, True, 0)(t), dr.timesteps_proj(t, 3072, True, 0), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 5, 8, 9])
+def test_temporal_index_maps_match_interpolate(T):
+    x = torch.arange(T, dtype=torch.float32)[None, None, :, None, None].expand(1, 1, T, 2, 2)
+    for compress in (True, False):
+        ref = dr.upsample3d_nearest(x, compress)[0, 0, :, 0, 0].long().tolist()
+        assert upsample_t_map(T, compress) == ref
+    for Tz in (1, 2, 3):
+        z = torch.arange(Tz, dtype=torch.float32)[None, None, :, None, None].expand(1, 1, Tz, 2, 2)
+        if T > 1 and T % 2 == 1:
+            if Tz < 2:
+                continue
+            first = F.interpolate(z[:, :, :1], size=(1, 2, 2))
+            rest = F.interpolate(z[:, :, 1:], size=(T - 1, 2, 2))
+            ref = torch.cat([first, rest], 2)
+        else:
+            ref = F.interpolate(z, size=(T, 2, 2))
+        assert zq_t_map(T, Tz) == ref[0, 0, :, 0, 0].long().tolist()
+
+
+def test_resize_mask_matches_oracle():
+    m = (torch.rand(1, 1, 9, 16, 24) > 0.5).float()
+    lat = torch.zeros(1, 16, 3, 2, 3)
+    torch.testing.assert_close(resize_mask(m, lat), opl.resize_mask(m, lat))
+
+
+def test_config_and_state_dict_round_trip(tmp_path):
+    cfg = dict(num_attention_heads=2, num_layers=2, in_channels=33, text_embed_dim=32, time_embed_dim=32,
+               use_rotary_positional_embeddings=True, is_train_cross=True, cross_attn_dim_head=64, cross_attn_num_heads=2)
+    m = CrossTransformer3DModel(**cfg)
+    assert m.config.patch_size == 2 and m.config["in_channels"] == 33 and m.config.num_layers == 2
+    sd = iw.random_state_dict(iw.transformer_param_shapes(dict(m.config)), 3)
+    m.load_state_dict(sd, strict=True)
+    m.save_pretrained(str(tmp_path / "tr"))
+    assert json.load(open(tmp_path / "tr" / "config.json"))["cross_attn_dim_head"] == 64
+    m2 = CrossTransformer3DModel.from_pretrained(str(tmp_path), subfolder="tr")
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    # reference from_pretrained_2d semantics: patch_embed input channels zero-padded when the checkpoint has fewer
+    small = dict(sd)
+    small["patch_embed.proj.weight"] = sd["patch_embed.proj.weight"][:, :16].clone()
+    from safetensors.torch import save_file
+    os.makedirs(tmp_path / "tr16")
+    save_file(small, str(tmp_path / "tr16" / "diffusion_pytorch_model.safetensors"))
+    json.dump(dict(m.config), open(tmp_path / "tr16" / "config.json", "w"))
+    m3 = CrossTransformer3DModel.from_pretrained_2d(str(tmp_path), subfolder="tr16")
+    w = m3.state_dict()["patch_embed.proj.weight"]
+    assert torch.equal(w[:, :16], small["patch_embed.proj.weight"]) and float(w[:, 16:].abs().max()) == 0
+    with pytest.raises(RuntimeError):
+        CrossTransformer3DModel.from_pretrained_2d(str(tmp_path / "nope"))
+    # attribute surface used by callers: length-dynamic module lists, processor API
+    assert len(m.transformer_blocks) == 2 and len(m.perceiver_cross_attention) == 1
+    assert len(m.attn_processors) == 2
+    with pytest.raises(ValueError):
+        m.set_attn_processor({"x": 1})
+    v = AutoencoderKLCogVideoX(block_out_channels=(8, 16, 16, 32), norm_num_groups=4, layers_per_block=1)
+    assert v.config.scaling_factor == 1.15258426 and list(v.config.block_out_channels) == [8, 16, 16, 32]
+    with pytest.raises(NotImplementedError):
+        v.enable_tiling()
+
+
+def test_pipeline_rejects_cpu_models_and_checks_inputs():
+    from trajectorycrafter_amd._lib import TcxError
+    tr = CrossTransformer3DModel(num_attention_heads=2, num_layers=1, in_channels=33, text_embed_dim=32, time_embed_dim=32,
+                                 use_rotary_positional_embeddings=True)
+    vae = AutoencoderKLCogVideoX(block_out_channels=(8, 16, 16, 32), norm_num_groups=4, layers_per_block=1)
+    pipe = TrajCrafter_Pipeline(None, None, vae, tr)
+    assert pipe.vae_scale_factor_spatial == 8 and pipe.vae_scale_factor_temporal == 4
+    pe = torch.zeros(1, 10, 32)
+    with pytest.raises(TcxError, match="no CPU fallback"):
+        pipe(prompt=None, prompt_embeds=pe, negative_prompt_embeds=pe, height=32, width=48, num_frames=9)
+    with pytest.raises(ValueError):
+        pipe(prompt="a", prompt_embeds=pe, height=32, width=48, num_frames=9)
+    with pytest.raises(ValueError, match="no text encoder"):
+        pipe.encode_prompt("hello", None, True, device="cpu")
