@@ -2,7 +2,7 @@
 //
 // Work decomposition: one 512-thread workgroup = 8 waves = 256 query rows of one (batch, head);
 // each wave owns 32 query rows.  K/V tiles of 64 keys are staged global -> registers -> LDS
-// (issue-early / write-late, double buffered, one barrier per tile).
+// (issue-early / write-late, ring of LDS slots, one barrier per 128 keys at D=64 / per 64 keys at D=128).
 //
 // MFMA plan (v_mfma_f32_32x32x16_bf16), "swapped" so that a query row lives on ONE lane:
 //   S^T[kv, q] = K[kv, :] . Q[q, :]      A = K rows (ds_read_b128 from an XOR-swizzled LDS image)
@@ -113,32 +113,38 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         klds[i] = k_off<D>(row, ch);
         vlds[i] = v_chunk_off<D>(row, ch);
     }
-    u32x4 kreg[NLD], vreg[NLD];
+    constexpr int TPB = (D == 64) ? 2 : 1;  // 64-key tiles per barrier / staging round (D = 128 has no registers for 2)
+    constexpr int R = 2 * TPB;              // LDS ring slots per operand; tile t lives in slot t % R
+    u32x4 kreg[TPB][NLD], vreg[TPB][NLD];
     const int ntiles = (p.Sk + 63) >> 6;
 
-    auto load_k = [&](int tile) {   // rows >= Sk read as zero (range check); tiles beyond the end too
+    auto load_k = [&](auto jc, int tile) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;   // rows >= Sk read as zero (range check); tiles beyond the end too
 #ifdef TCX_EXP_NOLOAD
-        if (tile > 2) return;
+        if (tile > 2 * R) return;
 #endif
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[i] + tile * ktile_bytes, 0, 0);
+        for (int i = 0; i < NLD; ++i) kreg[j][i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[i] + tile * ktile_bytes, 0, 0);
     };
-    auto load_v = [&](int tile) {   // zero V rows beyond Sk: P = 0 never meets garbage
+    auto load_v = [&](auto jc, int tile) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;   // zero V rows beyond Sk: P = 0 never meets garbage
 #ifdef TCX_EXP_NOLOAD
-        if (tile > 2) return;
+        if (tile > 2 * R) return;
 #endif
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[i] + tile * vtile_bytes, 0, 0);
+        for (int i = 0; i < NLD; ++i) vreg[j][i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[i] + tile * vtile_bytes, 0, 0);
     };
     char* const kbuf0 = smem;
-    char* const vbuf0 = smem + 2 * TILEB;
-    auto write_k = [&](int buf) {
+    char* const vbuf0 = smem + R * TILEB;
+    auto write_k = [&](auto jc, int slot) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(kbuf0 + buf * TILEB + klds[i]) = kreg[i];
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(kbuf0 + slot * TILEB + klds[i]) = kreg[j][i];
     };
-    auto write_v = [&](int buf) {
+    auto write_v = [&](auto jc, int slot) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(vbuf0 + buf * TILEB + vlds[i]) = vreg[i];
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(vbuf0 + slot * TILEB + vlds[i]) = vreg[j][i];
     };
 
     // ---- per-lane LDS read bases (everything else is a compile-time immediate) ----
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     float ls[4] = {0.f, 0.f, 0.f, 0.f};   // per-lane partial row sums since the last rescale (VALU row-sum paths)
 
     // S^T tile of one 64-key block: 2 x (32 keys x 32 queries); `ks0..ks1` selects a slice of the k-steps
-    auto qk_init = [&](f32x16 (&s)[2]) {
+    auto qk_init = [&](f32x16 (&s)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if constexpr (FAST) s[t] = minit;      // S' = K Q^T - m straight out of the MFMA chain
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             }
         }
     };
-    auto qk_part = [&](const char* kb, f32x16 (&s)[2], int ks0, int ks1) {
+    auto qk_part = [&](const char* kb, f32x16 (&s)[2], int ks0, int ks1) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = ks0; ks < ks1; ++ks) {
 #pragma unroll
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     };
 
     // running max of a freshly computed tile, then the (deferred, rare) rescale of O and l
-    auto row_max_and_rescale = [&](f32x16 (&s)[2]) {
+    auto row_max_and_rescale = [&](f32x16 (&s)[2]) __attribute__((always_inline)) {
         float m0 = s[0][0], m1 = s[0][1], m2 = s[1][0], m3 = s[1][1];   // 4 independent v_max3 chains
 #pragma unroll
         for (int i = 2; i < 16; i += 4) {
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     // finished next tile is max-checked at the end, under the tail of the PV MFMAs.
     constexpr int KPS = KS / 4;                      // k-steps of the next tile's QK^T per 16-key step
     // LDS -> register fragment reads of one 16-key step (issued one step ahead of their MFMAs)
-    auto read_frags = [&](auto has_next, const char* kb, const char* vb, int st, bf16x8 (&kf)[KPS][2], bf16x8 (&vf)[DT]) {
+    auto read_frags = [&](auto has_next, const char* kb, const char* vb, int st, bf16x8 (&kf)[KPS][2], bf16x8 (&vf)[DT]) __attribute__((always_inline)) {
         constexpr bool NEXT = decltype(has_next)::value;
         if constexpr (NEXT) {
 #pragma unroll
@@ -301,13 +307,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 #endif
         }
     };
-    auto tile_body = [&](auto has_next, const char* kb, const char* vb, f32x16 (&cur)[2], f32x16 (&nxt)[2]) {
+    auto tile_body = [&](auto has_next, const char* kb, const char* vb, f32x16 (&cur)[2], f32x16 (&nxt)[2]) __attribute__((always_inline)) {
         constexpr bool NEXT = decltype(has_next)::value;
         constexpr bool PREF = (D == 64);             // D = 128 has no registers to spare for a second fragment set
         bf16x8 kfa[KPS][2], kfb[KPS][2], vfa[DT], vfb[DT];
         if constexpr (PREF) read_frags(has_next, kb, vb, 0, kfa, vfa);
         if constexpr (NEXT) qk_init(nxt);
-        auto one_step = [&](int st, bf16x8 (&kf)[KPS][2], bf16x8 (&vf)[DT], bf16x8 (&kfn)[KPS][2], bf16x8 (&vfn)[DT]) {
+        auto one_step = [&](int st, bf16x8 (&kf)[KPS][2], bf16x8 (&vf)[DT], bf16x8 (&kfn)[KPS][2], bf16x8 (&vfn)[DT]) __attribute__((always_inline)) {
             const int t = st >> 1, s2 = st & 1;
             if constexpr (PREF) {
                 if (st < 3) read_frags(has_next, kb, vb, st + 1, kfn, vfn);  // next step's operands, in flight under this step
@@ -360,53 +366,100 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         }
     };
 
-    // Software pipeline.  LDS: K and V are each double buffered but one tile apart — step(t) reads
-    // Kbuf[(t+1)&1] and Vbuf[t&1]; global loads of K[t+2] / V[t+1] are issued at the top and written after
-    // the compute; one barrier per tile.  PAR = t & 1 is a template constant (loop unrolled by two).
+    // Software pipeline over 64-key tiles; staging and synchronisation in rounds of TPB tiles ("super-steps").
+    // Tile t lives in ring slot t % R of its operand.  At the start of the super-step of tiles t0 .. t0+TPB-1 the
+    // ring holds K[t0+1 .. t0+TPB] and V[t0 .. t0+TPB-1]; the super-step issues the global loads of
+    // K[t0+TPB+1 .. t0+2TPB] and V[t0+TPB .. t0+2TPB-1] at its top, runs its tiles (tile t: S(t+1) from K[t+1]
+    // interleaved with softmax/PV of tile t from V[t]), then writes the loaded tiles into the slots their
+    // predecessors have just vacated, and ends with the only barrier.  PH = t0 % R is a template constant, so
+    // every LDS address is base register + immediate.
+    constexpr std::integral_constant<int, 0> J0{};
+    constexpr std::integral_constant<int, TPB - 1> J1{};
     f32x16 sa[2], sb[2];
-    auto step = [&](auto par, int tile, f32x16 (&cur)[2], f32x16 (&nxt)[2]) {
-        constexpr int PAR = decltype(par)::value;
-        load_k(tile + 2);
-        load_v(tile + 1);
-        tile_body(std::true_type{}, kbuf0 + (PAR ^ 1) * TILEB, vbuf0 + PAR * TILEB, cur, nxt);
+    auto one_tile = [&](auto slot_k, auto slot_v, int tile, f32x16 (&cur)[2], f32x16 (&nxt)[2]) __attribute__((always_inline)) {
+        tile_body(std::true_type{}, kbuf0 + decltype(slot_k)::value * TILEB, vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
         if (tile + 1 == ntiles - 1 && (p.Sk & 63)) mask_tail(nxt);
         row_max_and_rescale(nxt);
+    };
+    auto super_step = [&](auto ph, int t0) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph)::value;
+        load_k(J0, t0 + TPB + 1);
+        load_v(J0, t0 + TPB);
+        if constexpr (TPB == 2) {
+            load_k(J1, t0 + TPB + 2);
+            load_v(J1, t0 + TPB + 1);
+        }
+        if constexpr (TPB == 2) {
+            one_tile(std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
+            one_tile(std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa);
+        } else {
+            if constexpr (PH == 0) one_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t0, sa, sb);
+            else one_tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t0, sb, sa);
+        }
 #ifndef TCX_EXP_NOWRITE
-        write_k(PAR);
-        write_v(PAR ^ 1);
+        write_k(J0, (PH + TPB + 1) % R);
+        write_v(J0, (PH + TPB) % R);
+        if constexpr (TPB == 2) {
+            write_k(J1, (PH + TPB + 2) % R);
+            write_v(J1, (PH + TPB + 1) % R);
+        }
 #endif
 #ifndef TCX_EXP_NOBARRIER
         __syncthreads();
 #endif
     };
+    // tiles left after the last full super-step: fewer than TPB steps with a successor (everything they read is
+    // already resident: no staging, no barrier), then the peeled last tile (no successor)
+    auto tail = [&](auto ph, int t0) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph)::value;
+        const int rem = (ntiles - 1) - t0;                   // 0 .. TPB-1
+        if constexpr (TPB == 2) {
+            if (rem == 1) {
+                one_tile(std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
+                tile_body(std::false_type{}, kbuf0, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
+            } else {
+                tile_body(std::false_type{}, kbuf0, vbuf0 + (PH % R) * TILEB, sa, sb);
+            }
+        } else {
+            (void)rem;
+            if constexpr (PH == 0) tile_body(std::false_type{}, kbuf0, vbuf0, sa, sb);
+            else tile_body(std::false_type{}, kbuf0, vbuf0 + TILEB, sb, sa);
+        }
+    };
 
-    load_k(0);
-    load_v(0);
-    write_k(0);
-    write_v(0);
-    load_k(1);
-    write_k(1);
+    // prologue: K[0 .. TPB], V[0 .. TPB-1] into their slots, S(0)
+    load_k(J0, 0);
+    load_v(J0, 0);
+    if constexpr (TPB == 2) {
+        load_k(J1, 1);
+        load_v(J1, 1);
+    }
+    write_k(J0, 0);
+    write_v(J0, 0);
+    if constexpr (TPB == 2) {
+        write_k(J1, 1);
+        write_v(J1, 1);
+    }
+    load_k(J0, TPB);
+    write_k(J0, TPB % R);
     __syncthreads();
     qk_init(sa);
     qk_part(kbuf0, sa, 0, KS);
     if (ntiles == 1 && (p.Sk & 63)) mask_tail(sa);
     row_max_and_rescale(sa);
-    __syncthreads();                      // K[0] may be overwritten from step 0 on
+    __syncthreads();                      // slot 0 of K is overwritten at the end of the first super-step
 
-    int tile = 0;
-    for (; tile + 2 <= ntiles - 1; tile += 2) {
-        step(std::integral_constant<int, 0>{}, tile, sa, sb);
-        step(std::integral_constant<int, 1>{}, tile + 1, sb, sa);
+    int t0 = 0;
+    for (; t0 + 2 * TPB <= ntiles - 1; t0 += 2 * TPB) {
+        super_step(std::integral_constant<int, 0>{}, t0);
+        super_step(std::integral_constant<int, TPB>{}, t0 + TPB);
     }
-    // ---- at most one more pipelined step, then the peeled last tile (no successor) ----
-    const bool odd = tile < ntiles - 1;
-    if (odd) step(std::integral_constant<int, 0>{}, tile, sa, sb);
-    f32x16 fin[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) fin[t][i] = odd ? sb[t][i] : sa[t][i];
-    tile_body(std::false_type{}, kbuf0, vbuf0 + ((ntiles - 1) & 1) * TILEB, fin, sa);
+    if (t0 + TPB <= ntiles - 1) {
+        super_step(std::integral_constant<int, 0>{}, t0);
+        tail(std::integral_constant<int, TPB>{}, t0 + TPB);
+    } else {
+        tail(std::integral_constant<int, 0>{}, t0);
+    }
     if constexpr (!(FAST && kSumMfma)) l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
 
     // ---- epilogue: combine the two half-wave partial sums, normalise, store O[q][d] ----
@@ -442,7 +495,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 
 template <int D, bool F32, bool FAST, int NW>
 int launch_nw(AttnParams p, hipStream_t st) {
-    constexpr int lds = 4 * 64 * D * 2;
+    constexpr int lds = 2 * (D == 64 ? 4 : 2) * 64 * D * 2;   // K ring + V ring, R slots each
     static bool attr_done = false;  // idempotent; racing threads set the same value
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, F32, FAST, NW>),
@@ -483,7 +536,7 @@ extern "C" int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o
         TCX_CHECK(st[i] % 8 == 0 && st[i] >= 0, TCX_E_ALIGN, "tcx_attn_fwd: stride %d (=%lld) must be a non-negative multiple of 8", i, (long long)st[i]);
     TCX_CHECK(kss >= D && vss >= D, TCX_E_SHAPE, "tcx_attn_fwd: k/v row stride must be >= D");
     // K / V of one (batch, head) are addressed with 32-bit buffer offsets (two tiles of look-ahead included)
-    TCX_CHECK(((int64_t)Sk + 192) * kss * 2 < (1ll << 31) && ((int64_t)Sk + 192) * vss * 2 < (1ll << 31), TCX_E_SHAPE,
+    TCX_CHECK(((int64_t)Sk + 448) * kss * 2 < (1ll << 31) && ((int64_t)Sk + 448) * vss * 2 < (1ll << 31), TCX_E_SHAPE,
               "tcx_attn_fwd: Sk * row stride exceeds the 2 GiB buffer-addressing range");
     AttnParams p;
     p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.v = (const uint16_t*)v; p.o = o;
