@@ -202,6 +202,11 @@ def main():
         avg_ms = sa["ms"] / max(sa["n"], 1)
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         fwd_flop = {(49, 480, 720): 3.5585e14, (49, 384, 672): 2.3387e14}.get((args.frames, args.height, args.width))
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r1_attn_pmc.json")        # PMC counters cannot be read inside the timed run:
+        if os.path.exists(pmc) and (args.frames, args.height, args.width) == (49, 480, 720):   # committed rocprofv3 --pmc result
+            with open(pmc) as f:
+                traffic = json.load(f).get("traffic_bytes_per_launch")
         rec = {
             "metric": "denoised video-latents/sec (49f, 480x720)", "value": world * args.steps / elapsed,
             "unit": "video-latents/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -216,7 +221,8 @@ def main():
                                                  2 * args.denoise_steps * fwd_flop * (args.layers / 42) / tm["denoise_s"] / 1e12 / PEAK_BF16_TFLOPS)},
             "roofline": {"kernel": "tcx_attn_fwd<64> (joint self-attention, 42 launches per step)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                         "traffic": None, "launches": sa["n"], "avg_launch_ms": avg_ms,
+                         "traffic": traffic, "traffic_source": "profiles/r1_attn_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
+                         "launches": sa["n"], "avg_launch_ms": avg_ms,
                          "algorithmic_flop_per_launch": flop_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
