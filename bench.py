@@ -155,13 +155,16 @@ def main():
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # rehearsal knobs (never set by the driver): run several ranks on ONE GPU with gloo to exercise the N > 1 control flow
+    if os.environ.get("TCX_BENCH_SINGLE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
     from trajectorycrafter_amd import dp, ops
 
     if world > 1:
-        dp.init_distributed("nccl")
+        dp.init_distributed(os.environ.get("TCX_DIST_BACKEND", "nccl"))
     pipe, tcfg = build_models(args, device)
     inp = make_inputs(args, device, seed=43 + rank)            # one independent trajectory per rank (seeds 43..50)
 
@@ -213,7 +216,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[2]: full 50-step DDIM (CFG 6, B=2 per step) + VAE decode, 49f 480x720, "
-                                   "random-init 42-layer CrossTransformer3D-5B (6.1 B params); one independent trajectory per GPU",
+                                   "random-init " + str(args.layers) + "-layer CrossTransformer3D (42 layers = the 6.1 B-param 5B model); one independent trajectory per GPU",
                        "frames": args.frames, "height": args.height, "width": args.width, "denoise_steps": args.denoise_steps,
                        "layers": args.layers, "vae_decode": not args.no_decode, "global_batch_clips": world,
                        "parallelism": f"dp{world}", "last_clip_denoise_s": tm["denoise_s"], "last_clip_decode_s": tm["decode_s"],

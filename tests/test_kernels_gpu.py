@@ -74,7 +74,8 @@ def assert_attn_close(got, ref, bound, rtol=1e-3, atol=1e-4):
 
 
 @pytest.mark.parametrize("D,B,H,Sq,Sk", [(64, 1, 2, 300, 333), (64, 2, 3, 513, 64), (128, 1, 2, 257, 200),
-                                         (128, 2, 1, 64, 450), (64, 1, 1, 1, 1)])
+                                         (128, 2, 1, 64, 450), (64, 1, 1, 1, 1), (64, 1, 1, 50, 128), (64, 1, 1, 50, 320),
+                                         (128, 1, 1, 30, 65), (128, 1, 1, 30, 192)])
 def test_attn_fwd_matches_oracle(ops, D, B, H, Sq, Sk):
     g = torch.Generator().manual_seed(D + Sq)
     q, k, v = (bf(torch.randn(B, s, H, D, generator=g)) for s in (Sq, Sk, Sk))
@@ -87,7 +88,8 @@ def test_attn_fwd_matches_oracle(ops, D, B, H, Sq, Sk):
     assert_bf16_close(o16, ref, extra=bound)
 
 
-@pytest.mark.parametrize("B,H,Sq,Sk", [(1, 2, 300, 333), (2, 3, 513, 64), (1, 1, 1, 1), (1, 2, 70, 129), (1, 1, 256, 2048)])
+@pytest.mark.parametrize("B,H,Sq,Sk", [(1, 2, 300, 333), (2, 3, 513, 64), (1, 1, 1, 1), (1, 2, 70, 129), (1, 1, 256, 2048),
+                                       (1, 1, 40, 128), (1, 2, 33, 100), (1, 1, 64, 300), (1, 1, 64, 449)])   # 2, 2, 5, 8 key tiles
 def test_attn_fwd_log2_scores_fast_path(ops, B, H, Sq, Sk):
     """TCX_ATTN_LOG2_SCORES (D = 64): q pre-multiplied by scale*log2(e); running max as the MFMA initial
     accumulator; row sum of the rounded P on the matrix pipe.  Oracle: dr.sdpa_log2."""
