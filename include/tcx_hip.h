@@ -51,6 +51,10 @@ int tcx_device_info(int device, int32_t out[4]);
  *   scale*log2(e) by tcx_qk_layernorm_rope): P = exp2(Q K^T - max), `scale` must be 1.  The self-attention
  *   product path uses it (it removes one FMA per score from a VALU-bound loop); the row sum is then taken
  *   over the bf16-rounded probabilities (on the matrix pipe).
+ * k_sqmax (optional, fp32 [B*H], only read with TCX_ATTN_LOG2_SCORES and D = 64): max over the keys of |k|^2 per
+ *   (batch, head), as written by tcx_qk_layernorm_rope.  It lets the kernel centre the softmax of a query row on
+ *   the Cauchy-Schwarz bound |q| * max|k| instead of tracking a running max (no max / rescale work in the loop);
+ *   rows whose bound is too large for that to be provably underflow-free use the exact tracking loop.
  * out_dtype: TCX_BF16 (product path) or TCX_F32 (test-only higher precision output). */
 #define TCX_ATTN_LOG2_SCORES 1
 int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o,
@@ -59,7 +63,7 @@ int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o,
                  int64_t k_stride_b, int64_t k_stride_s, int64_t k_stride_h,
                  int64_t v_stride_b, int64_t v_stride_s, int64_t v_stride_h,
                  int64_t o_stride_b, int64_t o_stride_s, int64_t o_stride_h,
-                 float scale, int32_t flags, int32_t out_dtype, void* stream);
+                 float scale, int32_t flags, const float* k_sqmax, int32_t out_dtype, void* stream);
 
 /* ---- K2: per-head LayerNorm(D=64) on q and k + 3-D RoPE on the video tokens, in place ---------
  * Replaces: attn.norm_q / attn.norm_k (LayerNorm(64, eps 1e-6, affine)) and apply_rotary_emb on
@@ -69,13 +73,15 @@ int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o,
  * q, k: bf16 [B, S, H, 64] views (same stride convention as tcx_attn_fwd).  gamma/beta: bf16 [64].
  * cos/sin: fp32 [S - text_len, 64] (may be null -> no rotation).  fp32 math, one rounding.
  * q_scale multiplies q (not k) in fp32 before that rounding: the self-attention path passes
- * head_dim^-1/2 * log2(e) so that the attention kernel consumes base-2 scores (1.0 = plain). */
+ * head_dim^-1/2 * log2(e) so that the attention kernel consumes base-2 scores (1.0 = plain).
+ * k_sqmax (optional, fp32 [B*H]): receives max over the tokens of |k|^2 of the ROUNDED keys per (batch, head)
+ * (zeroed by this call on the stream, then float atomic max); input of tcx_attn_fwd's bound-centred loop. */
 int tcx_qk_layernorm_rope(void* q, void* k,
                           int32_t B, int32_t S, int32_t H, int32_t D,
                           int64_t stride_b, int64_t stride_s, int64_t stride_h,
                           const void* gamma_q, const void* beta_q, const void* gamma_k, const void* beta_k,
                           const float* cos, const float* sin, int32_t text_len, float eps, float q_scale,
-                          void* stream);
+                          float* k_sqmax, void* stream);
 
 /* ---- K4: LayerNorm (+ optional AdaLN modulate) over rows of C channels ------------------------
  * y = LN(x) * gamma + beta, then optionally y = y * (1 + scale[b]) + shift[b], with separate

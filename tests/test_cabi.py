@@ -30,13 +30,13 @@ def test_argument_validation_without_gpu():
     from trajectorycrafter_amd import _lib
     lib = _lib.load()
     # null pointers / bad head dim are rejected before any launch
-    rc = lib.tcx_attn_fwd(None, None, None, None, 1, 1, 8, 8, 64, *([64] * 12), 1.0, 0, 0, None)
+    rc = lib.tcx_attn_fwd(None, None, None, None, 1, 1, 8, 8, 64, *([64] * 12), 1.0, 0, None, 0, None)
     assert rc == -4 and b"null" in lib.tcx_last_error_string()
     buf = ctypes.create_string_buffer(4096)
     p = (ctypes.addressof(buf) + 15) & ~15
-    rc = lib.tcx_attn_fwd(p, p, p, p, 1, 1, 8, 8, 32, *([64] * 12), 1.0, 0, 0, None)
+    rc = lib.tcx_attn_fwd(p, p, p, p, 1, 1, 8, 8, 32, *([64] * 12), 1.0, 0, None, 0, None)
     assert rc == -1 and b"head dim" in lib.tcx_last_error_string()
-    rc = lib.tcx_attn_fwd(p + 2, p, p, p, 1, 1, 8, 8, 64, *([64] * 12), 1.0, 0, 0, None)
+    rc = lib.tcx_attn_fwd(p + 2, p, p, p, 1, 1, 8, 8, 64, *([64] * 12), 1.0, 0, None, 0, None)
     assert rc == -3
     rc = lib.tcx_layernorm_modulate(p, p, 1, 4, 12, 48, 48, None, None, None, None, None, None, 0, 0, 1e-5, None)
     assert rc == -1                       # C % 8 != 0

@@ -108,6 +108,12 @@ def test_attn_fwd_log2_scores_fast_path(ops, B, H, Sq, Sk):
     assert_bf16_close(o16, ref, extra=bound)
     with pytest.raises(ops.TcxError):
         ops.attn_fwd(dev(q), dev(k), dev(v), 0.125, log2_scores=True)       # scale must be 1 with the flag
+    # bound-centred loop (softmax centred on |q| max|k| from k_sqmax): same contract, same tolerance
+    ksq = dev((k.float() ** 2).sum(-1).amax(1).contiguous())                # [B, H]
+    o32b = ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, out_dtype=torch.float32, log2_scores=True, k_sqmax=ksq)
+    assert_attn_close(o32b, ref, bound)
+    o16b = ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, log2_scores=True, k_sqmax=ksq)
+    assert_bf16_close(o16b, ref, extra=bound)
 
 
 def test_attn_fwd_fast_path_forced_recentre(ops):
@@ -125,6 +131,29 @@ def test_attn_fwd_fast_path_forced_recentre(ops):
     pr = torch.softmax(torch.matmul(qt, kt.transpose(-1, -2)) * math.log(2.0), dim=-1)
     bound = 3 * (2.0 ** -9) * torch.matmul(pr, vt.abs()).transpose(1, 2).contiguous()
     o = ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, out_dtype=torch.float32, log2_scores=True)
+    assert_attn_close(o, ref, bound)
+    # with k_sqmax: the spiked keys push the Cauchy-Schwarz bound of these rows beyond 60 -> the workgroup is
+    # handed to the exact kernel (complementary launch); result must be the same
+    ksq = dev((k.float() ** 2).sum(-1).amax(1).contiguous())
+    assert float(ksq.max()) * float((q.float() ** 2).sum(-1).max()) > 60.0 ** 2
+    ob = ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, out_dtype=torch.float32, log2_scores=True, k_sqmax=ksq)
+    assert_attn_close(ob, ref, bound)
+
+
+def test_attn_fwd_bound_mixed_workgroups(ops):
+    """Some 256-row workgroups safe (bound loop), one with a huge-norm query row (exact loop): every row correct."""
+    g = torch.Generator().manual_seed(23)
+    B, H, S, D = 1, 2, 700, 64
+    q, k, v = (bf(torch.randn(B, S, H, D, generator=g)) for _ in range(3))
+    q = bf(q.float() * 0.18)
+    q[0, 300, 1] *= 40.0                              # M = |q||k|max ~ 1.4*40*10 >> 60 for the workgroup of rows 256..511, head 1
+    qt, kt, vt = q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)
+    ref = dr.sdpa_log2(Prec("bf16"), qt, kt, vt).transpose(1, 2).contiguous()
+    pr = torch.softmax(torch.matmul(qt, kt.transpose(-1, -2)) * math.log(2.0), dim=-1)
+    bound = 3 * (2.0 ** -9) * torch.matmul(pr, vt.abs()).transpose(1, 2).contiguous()
+    dk = dev(k)
+    ksq = dev((k.float() ** 2).sum(-1).amax(1).contiguous())
+    o = ops.attn_fwd(dev(q), dk, dev(v), 1.0, out_dtype=torch.float32, log2_scores=True, k_sqmax=ksq)
     assert_attn_close(o, ref, bound)
 
 
@@ -219,9 +248,12 @@ def test_qk_layernorm_rope(ops, B, S, H, text_len):
     # q_scale: q (only) leaves pre-multiplied, one rounding
     d = dev(qkv)
     dq, dk, dv = (t.view(B, S, H, D) for t in d.chunk(3, -1))
-    ops.qk_layernorm_rope(dq, dk, dev(gq), dev(bq), dev(gk), dev(bk), dev(cos), dev(sin), text_len, 1e-6, q_scale=0.18033688)
+    ksq = ops.qk_layernorm_rope(dq, dk, dev(gq), dev(bq), dev(gk), dev(bk), dev(cos), dev(sin), text_len, 1e-6,
+                                q_scale=0.18033688, want_k_sqmax=True)
     assert_bf16_close(dq, rq * 0.18033688)
     assert_bf16_close(dk, rk)
+    # k_sqmax = max over tokens of |k|^2 of the stored (rounded) keys, per (batch, head): exact up to fp32 summation order
+    torch.testing.assert_close(ksq.cpu(), (dk.float().cpu() ** 2).sum(-1).amax(1), rtol=1e-5, atol=1e-5)
 
 
 def test_gated_residual_and_plain_residual(ops):

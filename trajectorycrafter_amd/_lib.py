@@ -22,8 +22,8 @@ SIGNATURES = {
     "tcx_version": [],
     "tcx_last_error_string": [],
     "tcx_device_info": [C.c_int, C.POINTER(_i32)],
-    "tcx_attn_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32] + [_i64] * 12 + [_f32, _i32, _i32, _vp],
-    "tcx_qk_layernorm_rope": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp],
+    "tcx_attn_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32] + [_i64] * 12 + [_f32, _i32, _vp, _i32, _vp],
+    "tcx_qk_layernorm_rope": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp],
     "tcx_layernorm_modulate": [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "tcx_gated_residual": [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _i64, _i32, _vp],
     "tcx_bias_gelu_tanh": [_vp, _vp, _vp, _i64, _i32, _vp],

@@ -43,6 +43,7 @@ struct AttnParams {
     int64_t qsb, qss, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, oss, osh;
     float scale_log2;
     uint32_t nqb, nwg;
+    const float* k_sqmax;   // [B*H] max_k |k|^2 (FAST path, optional): enables the bound-centred loop
 };
 
 #ifndef TCX_ATTN_SUM_MFMA
@@ -68,8 +69,9 @@ __device__ __forceinline__ int v_chunk_off(int row, int ch) {
         return row * 256 + ((ch ^ ((row & 3) << 2)) << 4);
 }
 
-template <int D, bool OUT_F32, bool FAST, int NW>
+template <int D, bool OUT_F32, bool FAST, int NW, bool BOUND>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
+    static_assert(!BOUND || FAST, "the bound-centred loop needs log2-domain scores");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CH = D / 8;              // 16-B chunks per row
     constexpr int TILEB = 64 * D * 2;      // bytes of one K (or V) tile
@@ -180,6 +182,41 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
     bool first = true;
     float ls[4] = {0.f, 0.f, 0.f, 0.f};   // per-lane partial row sums since the last rescale (VALU row-sum paths)
+    // Bound-centred variant of the FAST path: with M = |q_row| * max_k |k| >= every score of the row
+    // (Cauchy-Schwarz; max_k |k|^2 per (batch, head) comes from the q/k-LayerNorm+RoPE kernel), P = exp2(S - M)
+    // is <= 1 for the whole sweep: no running max, no per-tile max3 chain, no rescale branch.  Floating-point
+    // P keeps its relative precision at any scale; the only hazard is underflow of a whole row, impossible while
+    // M - max_k S <= 2 M < 120, so the wave falls back to the exact tracking loop if any of its rows has M >= 60.
+    // Two launches share the work when k_sqmax is given: the BOUND kernel takes the workgroups whose 256 rows all
+    // have M < 60 and returns at once otherwise; the exact kernel (BOUND = false) makes the same test and takes
+    // the complement.  The predicate is workgroup-uniform and evaluated before any other barrier.
+    constexpr bool bounded = BOUND;
+    if constexpr (FAST) {
+        if (p.k_sqmax) {
+            float qsq = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float qv = (float)qf[ks][j];
+                    qsq = __builtin_fmaf(qv, qv, qsq);
+                }
+            const uint32_t u = __float_as_uint(qsq);
+            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            qsq = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            const float M = sqrtf(qsq * p.k_sqmax[bh]) * 1.002f + 1e-3f;
+            const bool safe = __syncthreads_and(M < 60.0f) != 0;
+            if constexpr (BOUND) {
+                if (!safe) return;
+                m = M;
+                first = false;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) minit[i] = -M;
+            } else {
+                if (safe) return;
+            }
+        }
+    }
 
     // S^T tile of one 64-key block: 2 x (32 keys x 32 queries); `ks0..ks1` selects a slice of the k-steps
     auto qk_init = [&](f32x16 (&s)[2]) __attribute__((always_inline)) {
@@ -351,6 +388,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pf, o[dt], 0, 0, 0);
 #endif
             if constexpr (FAST && kSumMfma) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);   // row sum on the matrix pipe
+            else asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]));   // pin the partial sums here: without a use
+            // inside the loop (bound-centred variant) the add chains get sunk to the loop end and 64 exponentials stay live
             __builtin_amdgcn_sched_barrier(0);       // keep the four steps in this order (no re-bunching)
         };
         if constexpr (PREF) {
@@ -376,12 +415,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     constexpr std::integral_constant<int, 0> J0{};
     constexpr std::integral_constant<int, TPB - 1> J1{};
     f32x16 sa[2], sb[2];
-    auto one_tile = [&](auto slot_k, auto slot_v, int tile, f32x16 (&cur)[2], f32x16 (&nxt)[2]) __attribute__((always_inline)) {
+    auto one_tile = [&](auto bnd, auto slot_k, auto slot_v, int tile, f32x16 (&cur)[2], f32x16 (&nxt)[2]) __attribute__((always_inline)) {
         tile_body(std::true_type{}, kbuf0 + decltype(slot_k)::value * TILEB, vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
         if (tile + 1 == ntiles - 1 && (p.Sk & 63)) mask_tail(nxt);
-        row_max_and_rescale(nxt);
+        if constexpr (!decltype(bnd)::value) row_max_and_rescale(nxt);   // bound-centred loop: the reference max never moves
+        else __builtin_amdgcn_sched_barrier(0);                         // keep tiles apart (register pressure)
     };
-    auto super_step = [&](auto ph, int t0) __attribute__((always_inline)) {
+    auto super_step = [&](auto bnd, auto ph, int t0) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph)::value;
         load_k(J0, t0 + TPB + 1);
         load_v(J0, t0 + TPB);
@@ -390,11 +430,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             load_v(J1, t0 + TPB + 1);
         }
         if constexpr (TPB == 2) {
-            one_tile(std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
-            one_tile(std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa);
+            one_tile(bnd, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
+            one_tile(bnd, std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa);
         } else {
-            if constexpr (PH == 0) one_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t0, sa, sb);
-            else one_tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t0, sb, sa);
+            if constexpr (PH == 0) one_tile(bnd, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t0, sa, sb);
+            else one_tile(bnd, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t0, sb, sa);
         }
 #ifndef TCX_EXP_NOWRITE
         write_k(J0, (PH + TPB + 1) % R);
@@ -410,12 +450,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     };
     // tiles left after the last full super-step: fewer than TPB steps with a successor (everything they read is
     // already resident: no staging, no barrier), then the peeled last tile (no successor)
-    auto tail = [&](auto ph, int t0) __attribute__((always_inline)) {
+    auto tail = [&](auto bnd, auto ph, int t0) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph)::value;
         const int rem = (ntiles - 1) - t0;                   // 0 .. TPB-1
         if constexpr (TPB == 2) {
             if (rem == 1) {
-                one_tile(std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
+                one_tile(bnd, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
                 tile_body(std::false_type{}, kbuf0, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
             } else {
                 tile_body(std::false_type{}, kbuf0, vbuf0 + (PH % R) * TILEB, sa, sb);
@@ -446,20 +486,23 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     qk_init(sa);
     qk_part(kbuf0, sa, 0, KS);
     if (ntiles == 1 && (p.Sk & 63)) mask_tail(sa);
-    row_max_and_rescale(sa);
+    if constexpr (!bounded) row_max_and_rescale(sa);
     __syncthreads();                      // slot 0 of K is overwritten at the end of the first super-step
 
-    int t0 = 0;
-    for (; t0 + 2 * TPB <= ntiles - 1; t0 += 2 * TPB) {
-        super_step(std::integral_constant<int, 0>{}, t0);
-        super_step(std::integral_constant<int, TPB>{}, t0 + TPB);
-    }
-    if (t0 + TPB <= ntiles - 1) {
-        super_step(std::integral_constant<int, 0>{}, t0);
-        tail(std::integral_constant<int, TPB>{}, t0 + TPB);
-    } else {
-        tail(std::integral_constant<int, 0>{}, t0);
-    }
+    auto run = [&](auto bnd) __attribute__((always_inline)) {
+        int t0 = 0;
+        for (; t0 + 2 * TPB <= ntiles - 1; t0 += 2 * TPB) {
+            super_step(bnd, std::integral_constant<int, 0>{}, t0);
+            super_step(bnd, std::integral_constant<int, TPB>{}, t0 + TPB);
+        }
+        if (t0 + TPB <= ntiles - 1) {
+            super_step(bnd, std::integral_constant<int, 0>{}, t0);
+            tail(bnd, std::integral_constant<int, TPB>{}, t0 + TPB);
+        } else {
+            tail(bnd, std::integral_constant<int, 0>{}, t0);
+        }
+    };
+    run(std::integral_constant<bool, BOUND>{});
     if constexpr (!(FAST && kSumMfma)) l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
 
     // ---- epilogue: combine the two half-wave partial sums, normalise, store O[q][d] ----
@@ -493,26 +536,30 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     }
 }
 
-template <int D, bool F32, bool FAST, int NW>
-int launch_nw(AttnParams p, hipStream_t st) {
+template <int D, bool F32, bool FAST, int NW, bool BOUND>
+int launch_one(AttnParams p, hipStream_t st) {
     constexpr int lds = 2 * (D == 64 ? 4 : 2) * 64 * D * 2;   // K ring + V ring, R slots each
     static bool attr_done = false;  // idempotent; racing threads set the same value
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, F32, FAST, NW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, F32, FAST, NW, BOUND>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     p.nqb = (uint32_t)((p.Sq + 32 * NW - 1) / (32 * NW));
     p.nwg = p.nqb * (uint32_t)(p.B * p.H);
-    hipLaunchKernelGGL((attn_fwd_kernel<D, F32, FAST, NW>), dim3(p.nwg), dim3(64 * NW), lds, st, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, F32, FAST, NW, BOUND>), dim3(p.nwg), dim3(64 * NW), lds, st, p);
     TCX_LAUNCH_RET();
 }
 
 template <int D, bool F32, bool FAST>
 int launch(const AttnParams& p, hipStream_t st) {
-    static const int nw = getenv("TCX_ATTN_NW") ? atoi(getenv("TCX_ATTN_NW")) : 8;
-    if (nw == 4) return launch_nw<D, F32, FAST, 4>(p, st);
-    return launch_nw<D, F32, FAST, 8>(p, st);
+    if constexpr (FAST) {
+        if (p.k_sqmax) {                                  // bound-centred kernel + exact kernel on the complement
+            const int rc = launch_one<D, F32, true, 8, true>(p, st);
+            if (rc != TCX_OK) return rc;
+        }
+    }
+    return launch_one<D, F32, FAST, 8, false>(p, st);
 }
 
 }  // namespace
@@ -521,7 +568,7 @@ extern "C" int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o
                             int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t D,
                             int64_t qsb, int64_t qss, int64_t qsh, int64_t ksb, int64_t kss, int64_t ksh,
                             int64_t vsb, int64_t vss, int64_t vsh, int64_t osb, int64_t oss, int64_t osh,
-                            float scale, int32_t flags, int32_t out_dtype, void* stream) {
+                            float scale, int32_t flags, const float* k_sqmax, int32_t out_dtype, void* stream) {
     TCX_CHECK(q && k && v && o, TCX_E_NULL, "tcx_attn_fwd: null pointer");
     TCX_CHECK((flags & ~TCX_ATTN_LOG2_SCORES) == 0, TCX_E_SHAPE, "tcx_attn_fwd: unknown flags 0x%x", flags);
     const bool log2s = (flags & TCX_ATTN_LOG2_SCORES) != 0;
@@ -544,6 +591,7 @@ extern "C" int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o
     p.qsb = qsb; p.qss = qss; p.qsh = qsh; p.ksb = ksb; p.kss = kss; p.ksh = ksh;
     p.vsb = vsb; p.vss = vss; p.vsh = vsh; p.osb = osb; p.oss = oss; p.osh = osh;
     p.scale_log2 = log2s ? 1.0f : scale * 1.4426950408889634f;
+    p.k_sqmax = (log2s && D == 64) ? k_sqmax : nullptr;
     TCX_CHECK((uint64_t)((Sq + 127) / 128) * B * H < (1ull << 31), TCX_E_SHAPE, "tcx_attn_fwd: grid too large");
     p.nqb = 0; p.nwg = 0;       // set per launch geometry
     hipStream_t s = (hipStream_t)stream;

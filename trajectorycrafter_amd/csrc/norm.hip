@@ -96,6 +96,7 @@ struct QkParams {
     float eps;
     int64_t nvec;
     float q_scale;
+    float* k_sqmax;
 };
 
 // 8 lanes per 64-wide head vector (8 bf16 = 16 B per lane); a wave covers 8 head vectors.
@@ -155,7 +156,23 @@ __global__ __launch_bounds__(256) void qk_ln_rope_kernel(const QkParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] *= p.q_scale;
     }
-    if (active) *reinterpret_cast<u32x4*>(base) = pack8(y);
+    const u32x4 packed = pack8(y);
+    if (active) *reinterpret_cast<u32x4*>(base) = packed;
+    if (p.k_sqmax) {          // max_k |k|^2 of the ROUNDED keys per (batch, head): the attention kernel's Cauchy-Schwarz bound
+        float r[8];
+        unpack8(packed, r);
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(r[e], r[e], ss);
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        ss += __shfl_xor(ss, 4, 64);
+        if (active && which && sub == 0) {
+            unsigned* dst = reinterpret_cast<unsigned*>(p.k_sqmax + (int64_t)b * p.H + hh);
+            const unsigned bits = __float_as_uint(ss);            // non-negative floats order like their bit patterns
+            if (bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
+        }
+    }
 }
 
 }  // namespace
@@ -194,7 +211,7 @@ extern "C" int tcx_qk_layernorm_rope(void* q, void* k, int32_t B, int32_t S, int
                                      int64_t sb, int64_t ss, int64_t sh,
                                      const void* gq, const void* bq, const void* gk, const void* bk,
                                      const float* cos, const float* sin, int32_t text_len, float eps, float q_scale,
-                                     void* stream) {
+                                     float* k_sqmax, void* stream) {
     TCX_CHECK(q && k && gq && bq && gk && bk, TCX_E_NULL, "tcx_qk_layernorm_rope: null pointer");
     TCX_CHECK(D == 64, TCX_E_SHAPE, "tcx_qk_layernorm_rope: head dim must be 64 (got %d)", D);
     TCX_CHECK(B > 0 && S > 0 && H > 0 && text_len >= 0 && text_len <= S, TCX_E_SHAPE, "tcx_qk_layernorm_rope: bad shape");
@@ -204,7 +221,11 @@ extern "C" int tcx_qk_layernorm_rope(void* q, void* k, int32_t B, int32_t S, int
                   tcx_aligned16(bk) && tcx_aligned16(cos) && tcx_aligned16(sin),
               TCX_E_ALIGN, "tcx_qk_layernorm_rope: pointers must be 16-byte aligned");
     QkParams p{(uint16_t*)q, (uint16_t*)k, B, S, H, sb, ss, sh, (const uint16_t*)gq, (const uint16_t*)bq,
-               (const uint16_t*)gk, (const uint16_t*)bk, cos, sin, text_len, eps, (int64_t)B * S * 2 * H, q_scale};
+               (const uint16_t*)gk, (const uint16_t*)bk, cos, sin, text_len, eps, (int64_t)B * S * 2 * H, q_scale, k_sqmax};
+    if (k_sqmax) {
+        hipError_t me = hipMemsetAsync(k_sqmax, 0, sizeof(float) * (size_t)B * H, (hipStream_t)stream);
+        if (me != hipSuccess) { tcx_set_error("tcx_qk_layernorm_rope: memset failed: %s", hipGetErrorString(me)); return (int)me; }
+    }
     const int64_t nblk = (p.nvec + 31) / 32;
     TCX_CHECK(nblk < (1ll << 31), TCX_E_SHAPE, "tcx_qk_layernorm_rope: grid too large");
     hipLaunchKernelGGL(qk_ln_rope_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);

@@ -178,9 +178,9 @@ class Attention(nn.Module):
         cos, sin = image_rotary_emb if image_rotary_emb is not None else (None, None)
         # q leaves the fused LN+RoPE kernel pre-multiplied by dh^-1/2 * log2(e): the attention kernel then
         # consumes base-2 scores (P = exp2(q k^T - max)), one FMA less per score in its VALU-bound loop
-        ops.qk_layernorm_rope(q, k, self.norm_q.weight, self.norm_q.bias, self.norm_k.weight, self.norm_k.bias,
-                              cos, sin, text_len, self.eps, q_scale=dh ** -0.5 * LOG2E)
-        o = ops.attn_fwd(q, k, v, 1.0, log2_scores=True)                       # [B,S,H,dh] contiguous
+        ksq = ops.qk_layernorm_rope(q, k, self.norm_q.weight, self.norm_q.bias, self.norm_k.weight, self.norm_k.bias,
+                                    cos, sin, text_len, self.eps, q_scale=dh ** -0.5 * LOG2E, want_k_sqmax=True)
+        o = ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq)          # [B,S,H,dh] contiguous
         return _linear(o.view(B, S, D), self.to_out[0].weight, self.to_out[0].bias)
 
 

@@ -57,10 +57,12 @@ def attn_timing_stop() -> dict:
 
 
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
-             out: Optional[torch.Tensor] = None, out_dtype=BF16, log2_scores: bool = False) -> torch.Tensor:
+             out: Optional[torch.Tensor] = None, out_dtype=BF16, log2_scores: bool = False,
+             k_sqmax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q [B,Sq,H,D], k/v [B,Sk,H,D] bf16 views -> o [B,Sq,H,D].
 
-    log2_scores: q k^T already is the base-2 exponent (q pre-multiplied by scale*log2(e)); scale must be 1."""
+    log2_scores: q k^T already is the base-2 exponent (q pre-multiplied by scale*log2(e)); scale must be 1.
+    k_sqmax: fp32 [B,H] max_k |k|^2 from `qk_layernorm_rope` (log2_scores + D=64 only): bound-centred softmax loop."""
     for n, t in (("q", q), ("k", k), ("v", v)):
         _need(t, n)
     B, Sq, H, D = q.shape
@@ -70,6 +72,10 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
     if out is None:
         out = torch.empty((B, Sq, H, D), device=q.device, dtype=out_dtype)
     _need(out, "out", out_dtype)
+    if k_sqmax is not None:
+        _need(k_sqmax, "k_sqmax", torch.float32)
+        if tuple(k_sqmax.shape) != (B, H) or not k_sqmax.is_contiguous():
+            raise TcxError(f"attn_fwd: k_sqmax must be contiguous fp32 [{B},{H}], got {tuple(k_sqmax.shape)}")
     lib = _lib.load()
     ev = None
     if _ATTN_TIMING is not None:
@@ -77,7 +83,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
         ev[0].record()
     check(lib.tcx_attn_fwd(_p(q), _p(k), _p(v), _p(out), B, H, Sq, Sk, D,
                            *_bshd_strides(q, "q"), *_bshd_strides(k, "k"), *_bshd_strides(v, "v"),
-                           *_bshd_strides(out, "out"), float(scale), _lib.TCX_ATTN_LOG2_SCORES if log2_scores else 0,
+                           *_bshd_strides(out, "out"), float(scale), _lib.TCX_ATTN_LOG2_SCORES if log2_scores else 0, _p(k_sqmax),
                            TCX_F32 if out_dtype == torch.float32 else TCX_BF16, _stream()), "tcx_attn_fwd")
     if ev is not None:
         ev[1].record()
@@ -85,8 +91,10 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
     return out
 
 
-def qk_layernorm_rope(q, k, gq, bq, gk, bk, cos, sin, text_len: int, eps: float = 1e-6, q_scale: float = 1.0) -> None:
-    """In-place per-head LayerNorm + RoPE on q, k [B,S,H,64] bf16 views; q additionally times q_scale."""
+def qk_layernorm_rope(q, k, gq, bq, gk, bk, cos, sin, text_len: int, eps: float = 1e-6, q_scale: float = 1.0,
+                      want_k_sqmax: bool = False) -> Optional[torch.Tensor]:
+    """In-place per-head LayerNorm + RoPE on q, k [B,S,H,64] bf16 views; q additionally times q_scale.
+    want_k_sqmax: also return fp32 [B,H] = max over tokens of |k|^2 (input of attn_fwd's bound-centred loop)."""
     _need(q, "q"); _need(k, "k")
     B, S, H, D = q.shape
     sq = _bshd_strides(q, "q")
@@ -97,8 +105,10 @@ def qk_layernorm_rope(q, k, gq, bq, gk, bk, cos, sin, text_len: int, eps: float 
         if cos.shape != (S - text_len, D) or not cos.is_contiguous() or not sin.is_contiguous():
             raise TcxError(f"qk_layernorm_rope: cos/sin must be contiguous [{S - text_len},{D}], got {tuple(cos.shape)}")
     lib = _lib.load()
+    ksq = torch.empty((B, H), device=q.device, dtype=torch.float32) if want_k_sqmax else None
     check(lib.tcx_qk_layernorm_rope(_p(q), _p(k), B, S, H, D, *sq, _p(gq), _p(bq), _p(gk), _p(bk), _p(cos), _p(sin),
-                                    text_len, float(eps), float(q_scale), _stream()), "tcx_qk_layernorm_rope")
+                                    text_len, float(eps), float(q_scale), _p(ksq), _stream()), "tcx_qk_layernorm_rope")
+    return ksq
 
 
 def _rows3(t: torch.Tensor, name: str) -> Tuple[int, int, int, int]:
