@@ -57,6 +57,9 @@ def load() -> C.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
+        # torch must load ITS HIP runtime first: libtcx_hip.so then binds to that already-loaded libamdhip64 (same
+        # soname) instead of pulling a second runtime from /opt/rocm into the process ("no ROCm-capable device").
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise TcxError(
                 f"{LIB_PATH} is missing: the HIP extension is the only compute path. "
