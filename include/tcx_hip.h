@@ -199,6 +199,19 @@ int tcx_ncthw_to_cl(const void* x, void* y, int32_t N, int32_t C, int64_t spatia
 int tcx_cl_to_ncthw_frames(const void* x, float* y, int32_t N, int32_t C, int64_t spatial, int64_t out_spatial_stride,
                            int64_t out_offset, void* stream);
 
+/* ---- f3: point-cloud render = forward warp by bilinear splatting, fp32 ---------------------------
+ * One call = Warper.forward_warp(frame1, mask1, depth1, T1, T2, K1, K2, mask=False, twice=False) of the reference
+ * (models/utils.py:220-293): compute_transformed_points (:350-421) then bilinear_splatting of the frame and of the
+ * transformed depth (:422-583), fused: project -> float-atomic splat of (r,g,b,depth,weight) -> resolve.
+ * frame [b,3,h,w], depth [b,1,h,w], mask1 [b,1,h,w] or null, all fp32 NCHW like the reference.
+ * mats: fp32 [b,30] = K1^-1 (9) | rows of [R|t] of T2 T1^-1 (12) | K2 (9), prepared by the host (tiny inverses).
+ * Outputs: flow [b,2,h,w], warped [b,3,h,w] in [-1,1] (-1 where empty), mask2 [b,1,h,w], wdepth [b,1,h,w].
+ * Workspace: tdepth [b,h,w] and acc fp32 [b*(h+2)*(w+2)*5 + 4] (zeroed by the call on the stream).
+ * Float atomics: matches the reference / oracle to ~1e-5, not bitwise. */
+int tcx_warp_forward(const float* frame, const float* mask1, const float* depth, const float* mats,
+                     float* flow, float* tdepth, float* acc, float* warped, float* mask2, float* wdepth,
+                     int32_t b, int32_t h, int32_t w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -420,5 +420,46 @@ def main():
               source="reference TrajCrafter_Pipeline.__call__"))
 
 
+def make_warp():
+    """warp_tiny.safetensors: the reference's own Warper.forward_warp(mask=False, twice=False) (models/utils.py:220-293)
+    on a seeded scene: two views, a camera that moves sideways + yaws, depth with a near slab (occlusion ordering).
+    models/utils.py imports cv2 / decord / skimage / torchvision at module level for its video IO helpers; none is used
+    by the Warper path, so absent ones are stubbed with empty modules (scaffolding, like the diffusers stubs)."""
+    if not os.path.isdir(REF):
+        raise SystemExit("make_golden.py needs /root/reference (build container only)")
+    import importlib
+    for name in ("cv2", "decord", "skimage", "skimage.io", "torchvision", "torchvision.transforms", "PIL", "PIL.Image",
+                 "matplotlib", "matplotlib.pyplot", "tqdm", "imageio"):
+        try:
+            importlib.import_module(name)
+        except Exception:
+            _mod(name, VideoReader=object, cpu=lambda *a: None, imread=None, ToTensor=object, Image=object)
+    sys.path.insert(0, REF)
+    from models.utils import Warper
+    g = torch.Generator().manual_seed(4242)
+    b, h, w = 2, 24, 40
+    frame = torch.rand(b, 3, h, w, generator=g) * 2 - 1
+    depth = 2.0 + torch.rand(b, 1, h, w, generator=g)
+    depth[:, :, 6:14, 10:22] = 0.8                                  # near slab: must win the splat where it lands
+    depth[1, :, 0:2, 0:3] = 1e-3
+    k = torch.tensor([[30.0, 0, w / 2], [0, 30.0, h / 2], [0, 0, 1]])[None].repeat(b, 1, 1)
+    t1 = torch.eye(4)[None].repeat(b, 1, 1)
+    t2 = torch.eye(4)[None].repeat(b, 1, 1)
+    for n, (yaw, tx, tz) in enumerate(((0.08, 0.25, -0.1), (-0.3, -0.6, 2.2))):   # second pose pushes points behind the camera
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        t2[n, :3, :3] = torch.tensor([[c, 0, s_], [0, 1, 0], [-s_, 0, c]], dtype=torch.float32)
+        t2[n, :3, 3] = torch.tensor([tx, 0.05, -tz])
+    with torch.no_grad():
+        warped, mask2, wdepth, flow = Warper(device="cpu").forward_warp(frame, None, depth, t1, t2, k, None, False, twice=False)
+    save("warp_tiny.safetensors",
+         dict(frame=frame, depth=depth, t1=t1, t2=t2, K=k, warped=warped.float(), mask2=mask2.float(),
+              warped_depth=wdepth.float(), flow=flow.float()),
+         dict(source="reference models/utils.py Warper.forward_warp(frame, None, depth, t1, t2, K, None, False, twice=False)", seed=4242))
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["warp"]:
+        make_warp()
+    else:
+        main()
+        make_warp()

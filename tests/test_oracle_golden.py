@@ -78,3 +78,16 @@ def test_pipeline_matches_reference(golden):
     frames = opl.pipeline_call(_weights(tt), tr_cfg, _weights(tv), vae_cfg, **kw)
     _close(frames, tp["frames"], rtol=1e-3, atol=1e-4)
     assert frames.shape == (1, 3, 9, 32, 48) and float(frames.min()) >= 0 and float(frames.max()) <= 1
+
+
+def test_forward_warp_matches_reference(golden):
+    """oracle.warp vs the reference's own Warper.forward_warp.  fp32 sums in a different order:
+    rtol 2e-5 (flow reaches 3.7e3 px for points pushed behind the camera) / atol 5e-5."""
+    from oracle import warp
+    t, _ = golden("warp_tiny.safetensors")
+    warped, mask2, wdepth, flow = warp.forward_warp(t["frame"], None, t["depth"], t["t1"], t["t2"], t["K"])
+    assert torch.equal(mask2, t["mask2"])
+    _close(flow, t["flow"], rtol=2e-5, atol=5e-5)
+    _close(warped, t["warped"], rtol=2e-5, atol=5e-5)
+    _close(wdepth, t["warped_depth"], rtol=2e-5, atol=5e-5)
+    assert 0.1 < float(mask2[1].mean()) < 0.3 and float(mask2[0].mean()) > 0.7     # the fixture has holes and occlusion

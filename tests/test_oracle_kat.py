@@ -161,3 +161,33 @@ def test_precision_modes_are_ordered():
     c = dr.layer_norm_zero(Prec("bf16"), sd, "", x.bfloat16().float(), e.bfloat16().float(), t.bfloat16().float(), 1e-5)[0]
     r = dr.layer_norm_zero(Prec("bf16_ref"), sd, "", x.bfloat16().float(), e.bfloat16().float(), t.bfloat16().float(), 1e-5)[0]
     assert (c - ref).abs().mean() <= (r - ref).abs().mean() * 1.05
+
+
+def test_forward_warp_identity_and_occlusion():
+    """Known answers for the point-cloud render (reference models/utils.py:220-293, 422-583):
+    same pose -> every pixel lands on itself; a one-pixel shift of a fronto-parallel plane moves the image by one
+    column and leaves the uncovered column at -1 / mask 0; of two surfaces landing on one pixel the nearer one wins
+    (weight 1/exp(50 log(1+d)/max))."""
+    from oracle import warp
+    g = torch.Generator().manual_seed(5)
+    b, h, w, f = 1, 6, 8, 10.0
+    frame = torch.rand(b, 3, h, w, generator=g) * 2 - 1
+    depth = torch.full((b, 1, h, w), 2.0)
+    k = torch.tensor([[f, 0, 4.0], [0, f, 3.0], [0, 0, 1]])[None]
+    eye = torch.eye(4)[None]
+    out, mask, wd, flow = warp.forward_warp(frame, None, depth, eye, eye, k)
+    assert float(flow.abs().max()) < 1e-5 and torch.equal(mask, torch.ones_like(mask))
+    torch.testing.assert_close(out, frame, rtol=0, atol=1e-5)
+    torch.testing.assert_close(wd, depth, rtol=0, atol=1e-5)
+    t2 = eye.clone()
+    t2[0, 0, 3] = 2.0 / f                                      # x' = x + f*tx/z = x + 1
+    out, mask, wd, flow = warp.forward_warp(frame, None, depth, eye, t2, k)
+    torch.testing.assert_close(flow[:, 0], torch.ones(b, h, w), rtol=0, atol=1e-5)
+    torch.testing.assert_close(out[..., 1:], frame[..., :-1], rtol=0, atol=2e-5)
+    # uncovered column: only rounding-size weights can land there
+    assert float(mask[..., 1:].min()) == 1.0
+    near = depth.clone()
+    near[..., 2] = 1.0                                         # column 2 is twice as close: shifts by 2, lands on column 4
+    out, mask, wd, _ = warp.forward_warp(frame, None, near, eye, t2, k)
+    torch.testing.assert_close(out[..., 4], frame[..., 2], rtol=0, atol=1e-4)      # far column 3 also lands there, loses
+    torch.testing.assert_close(wd[..., 4], torch.ones(b, 1, h), rtol=0, atol=1e-4)

@@ -1,0 +1,126 @@
+// Point-cloud render: forward warp of a frame into a new view by bilinear splatting.
+// Replaces the 49 sequential torch splats of Warper.forward_warp (reference models/utils.py:220-293, 350-583; 8
+// index_put_(accumulate=True) each) with three HBM/atomic-bound kernels, fp32 like the reference:
+//   project : per source pixel  K2 [R|t] (depth K1^-1 (x,y,1)) -> flow, target depth; max of log(1+depth) by atomic max
+//   splat   : per source pixel 4 corners x 5 floats (r, g, b, depth, weight) of float atomic adds into a padded
+//             (h+2) x (w+2) accumulator (one 20-byte record per target pixel: the five adds of a corner share a line)
+//   resolve : normalise, clamp, mask.
+// Float atomics commute only up to rounding: results match the oracle to ~1e-5, not bitwise (the reference's own
+// index_put_ accumulate on a GPU has the same property).
+#include "tcx_common.h"
+
+namespace {
+
+struct WarpParams {
+    const float *frame, *mask1, *depth, *mats;
+    float *flow, *tdepth, *acc, *warped, *mask2, *wdepth;
+    unsigned* logmax;
+    int32_t b, h, w;
+};
+
+// mats[n] = { K1inv (9, row major), Rel (12: 3 x 4 rows of [R|t]), K2 (9) }
+__global__ __launch_bounds__(256) void warp_project_kernel(const WarpParams p) {
+    const int64_t total = (int64_t)p.b * p.h * p.w;
+    float lmax = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % p.w), y = (int)((i / p.w) % p.h), n = (int)(i / ((int64_t)p.w * p.h));
+        const float* m = p.mats + 30 * n;
+        const float fx = (float)x, fy = (float)y, d = p.depth[i];
+        float ray[3], cam[3], pr[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) ray[r] = (m[3 * r] * fx + m[3 * r + 1] * fy + m[3 * r + 2]) * d;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) cam[r] = (m[9 + 4 * r] * ray[0] + m[9 + 4 * r + 1] * ray[1] + m[9 + 4 * r + 2] * ray[2]) + m[9 + 4 * r + 3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) pr[r] = m[21 + 3 * r] * cam[0] + m[21 + 3 * r + 1] * cam[1] + m[21 + 3 * r + 2] * cam[2];
+        if (cam[2] <= 0.01f) pr[0] = pr[1] = pr[2] = 1000.0f;                  // behind the target camera (:403-417)
+        const int64_t hw = (int64_t)p.h * p.w, pix = i - (int64_t)n * hw;
+        p.flow[(2 * (int64_t)n) * hw + pix] = pr[0] / pr[2] - fx;
+        p.flow[(2 * (int64_t)n + 1) * hw + pix] = pr[1] / pr[2] - fy;
+        p.tdepth[i] = pr[2];
+        lmax = fmaxf(lmax, logf(1.0f + fminf(fmaxf(pr[2], 0.f), 1000.0f)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(p.logmax, __float_as_uint(lmax));   // non-negative floats order like their bits
+}
+
+__global__ __launch_bounds__(256) void warp_splat_kernel(const WarpParams p) {
+    const int64_t hw = (int64_t)p.h * p.w, total = (int64_t)p.b * hw;
+    const float inv_logmax = 1.0f / __uint_as_float(*p.logmax);
+    const int W2 = p.w + 2, H2 = p.h + 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % p.w), y = (int)((i / p.w) % p.h), n = (int)(i / hw);
+        const int64_t pix = i - (int64_t)n * hw;
+        const float td = p.tdepth[i];
+        float px = p.flow[(2 * (int64_t)n) * hw + pix] + (float)x + 1.0f;       // +1: border of the padded accumulator
+        float py = p.flow[(2 * (int64_t)n + 1) * hw + pix] + (float)y + 1.0f;
+        const float lim_x = (float)(p.w + 1), lim_y = (float)(p.h + 1);
+        // floor / ceil BEFORE clamping, each then clamped on its own (reference :455-476)
+        const float flx = fminf(fmaxf(floorf(px), 0.f), lim_x), fly = fminf(fmaxf(floorf(py), 0.f), lim_y);
+        const float cex = fminf(fmaxf(ceilf(px), 0.f), lim_x), cey = fminf(fmaxf(ceilf(py), 0.f), lim_y);
+        px = fminf(fmaxf(px, 0.f), lim_x);
+        py = fminf(fmaxf(py, 0.f), lim_y);
+        const float dfx = px - flx, dfy = py - fly, dcx = cex - px, dcy = cey - py;
+        const float dw = expf(logf(1.0f + fminf(fmaxf(td, 0.f), 1000.0f)) * inv_logmax * 50.0f);
+        const float base = (p.mask1 ? p.mask1[i] : 1.0f) / dw;
+        const float v[4] = {p.frame[(3 * (int64_t)n) * hw + pix], p.frame[(3 * (int64_t)n + 1) * hw + pix],
+                            p.frame[(3 * (int64_t)n + 2) * hw + pix], td};
+        const int ix[2] = {(int)flx, (int)cex}, iy[2] = {(int)fly, (int)cey};
+        const float wx[2] = {1.0f - dfx, 1.0f - dcx}, wy[2] = {1.0f - dfy, 1.0f - dcy};
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+                const float wgt = wy[cy] * wx[cx] * base;
+                float* dst = p.acc + (((int64_t)n * H2 + iy[cy]) * W2 + ix[cx]) * 5;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) atomicAdd(dst + c, v[c] * wgt);
+                atomicAdd(dst + 4, wgt);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void warp_resolve_kernel(const WarpParams p) {
+    const int64_t hw = (int64_t)p.h * p.w, total = (int64_t)p.b * hw;
+    const int W2 = p.w + 2, H2 = p.h + 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % p.w), y = (int)((i / p.w) % p.h), n = (int)(i / hw);
+        const int64_t pix = i - (int64_t)n * hw;
+        const float* a = p.acc + (((int64_t)n * H2 + y + 1) * W2 + x + 1) * 5;
+        const float wsum = a[4];
+        const bool hit = wsum > 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float o = hit ? a[c] / wsum : -1.0f;
+            p.warped[(3 * (int64_t)n + c) * hw + pix] = fminf(fmaxf(o, -1.0f), 1.0f);
+        }
+        p.wdepth[i] = hit ? a[3] / wsum : 0.0f;
+        p.mask2[i] = hit ? 1.0f : 0.0f;
+    }
+}
+
+inline unsigned wgrid(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (unsigned)(b > 256 * 8 ? 256 * 8 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int tcx_warp_forward(const float* frame, const float* mask1, const float* depth, const float* mats,
+                                float* flow, float* tdepth, float* acc, float* warped, float* mask2, float* wdepth,
+                                int32_t b, int32_t h, int32_t w, void* stream) {
+    TCX_CHECK(frame && depth && mats && flow && tdepth && acc && warped && mask2 && wdepth, TCX_E_NULL, "tcx_warp_forward: null pointer");
+    TCX_CHECK(b > 0 && h > 0 && w > 0, TCX_E_SHAPE, "tcx_warp_forward: empty shape");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t acc_bytes = sizeof(float) * ((size_t)b * (h + 2) * (w + 2) * 5 + 4);     // + one 16-byte slot: max log-depth
+    hipError_t e = hipMemsetAsync(acc, 0, acc_bytes, st);
+    if (e != hipSuccess) { tcx_set_error("tcx_warp_forward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    WarpParams p{frame, mask1, depth, mats, flow, tdepth, acc, warped, mask2, wdepth,
+                 reinterpret_cast<unsigned*>(acc + (size_t)b * (h + 2) * (w + 2) * 5), b, h, w};
+    const int64_t total = (int64_t)b * h * w;
+    hipLaunchKernelGGL(warp_project_kernel, dim3(wgrid(total)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(warp_splat_kernel, dim3(wgrid(total)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(warp_resolve_kernel, dim3(wgrid(total)), dim3(256), 0, st, p);
+    TCX_LAUNCH_RET();
+}

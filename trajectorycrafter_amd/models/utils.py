@@ -1,0 +1,45 @@
+"""MI355X-native `Warper` — the point-cloud render of reference models/utils.py:213-293.
+
+Only the path the reference's `inference.py` takes by default is built: `forward_warp(..., mask=False, twice=False)`
+(`--mask` is off by default, inference.py:49; `clean_points` needs cv2).  The 4x4 / 3x3 inverses are tiny host-side
+torch ops; projection, splatting (float atomics) and normalisation are HIP kernels (`tcx_warp_forward`)."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from .. import ops
+from .._lib import TcxError
+
+
+class Warper:
+    def __init__(self, resolution: tuple = None, device: str = "cuda:0"):
+        self.resolution = resolution
+        self.device = torch.device("cuda:0" if device in ("gpu0", "cuda") else device)
+        self.dtype = torch.float32
+
+    def forward_warp(self, frame1: torch.Tensor, mask1: Optional[torch.Tensor], depth1: torch.Tensor,
+                     transformation1: torch.Tensor, transformation2: torch.Tensor, intrinsic1: torch.Tensor,
+                     intrinsic2: Optional[torch.Tensor], mask=False, twice=False
+                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """reference :220-293 -> (warped_frame2 [b,3,h,w] in [-1,1], mask2 [b,1,h,w], warped_depth2 [b,1,h,w], flow12 [b,2,h,w])."""
+        if mask or twice:
+            raise NotImplementedError("only forward_warp(mask=False, twice=False) — the reference's default path — is built")
+        if self.device.type != "cuda":
+            raise TcxError("Warper: the HIP splat needs a GPU device (no CPU fallback; use oracle.warp on the CPU)")
+        if self.resolution is not None:
+            assert tuple(frame1.shape[2:4]) == tuple(self.resolution)
+        b, c, h, w = frame1.shape
+        assert frame1.shape == (b, 3, h, w) and depth1.shape == (b, 1, h, w)
+        assert transformation1.shape == (b, 4, 4) and transformation2.shape == (b, 4, 4) and intrinsic1.shape == (b, 3, 3)
+        if mask1 is not None:
+            assert mask1.shape == (b, 1, h, w)
+        if intrinsic2 is None:
+            intrinsic2 = intrinsic1
+        to = dict(device=self.device, dtype=self.dtype)
+        t1, t2, k1, k2 = (t.to(**to) for t in (transformation1, transformation2, intrinsic1, intrinsic2))
+        rel = torch.bmm(t2, torch.linalg.inv(t1))                                 # :365-367
+        mats = torch.cat([torch.linalg.inv(k1).reshape(b, 9), rel[:, :3, :].reshape(b, 12), k2.reshape(b, 9)], dim=1).contiguous()
+        return ops.warp_forward(frame1.to(**to).contiguous(), None if mask1 is None else mask1.to(**to).contiguous(),
+                                depth1.to(**to).contiguous(), mats)

@@ -334,3 +334,23 @@ def cl_to_frames(x: torch.Tensor, out: torch.Tensor, t_offset: int) -> None:
         raise TcxError("cl_to_frames: bad output tensor")
     check(_lib.load().tcx_cl_to_ncthw_frames(_p(x), _p(out), N, Cc, T * H * W, out.shape[2] * H * W, t_offset * H * W,
                                              _stream()), "tcx_cl_to_ncthw_frames")
+
+
+# ----------------------------------------------------------------------------- point-cloud render
+def warp_forward(frame: torch.Tensor, mask1: Optional[torch.Tensor], depth: torch.Tensor, mats: torch.Tensor):
+    """frame [b,3,h,w], depth [b,1,h,w], mask1 [b,1,h,w] | None, mats [b,30] (all fp32, GPU, contiguous)
+    -> (warped [b,3,h,w], mask2 [b,1,h,w], warped_depth [b,1,h,w], flow [b,2,h,w])."""
+    for n, t in (("frame", frame), ("depth", depth), ("mats", mats)) + ((("mask1", mask1),) if mask1 is not None else ()):
+        _need(t, n, torch.float32)
+        if not t.is_contiguous():
+            raise TcxError(f"warp_forward: {n} must be contiguous")
+    b, c, h, w = frame.shape
+    if c != 3 or tuple(depth.shape) != (b, 1, h, w) or tuple(mats.shape) != (b, 30) or (mask1 is not None and tuple(mask1.shape) != (b, 1, h, w)):
+        raise TcxError("warp_forward: shape mismatch")
+    f32 = dict(device=frame.device, dtype=torch.float32)
+    flow, tdepth = torch.empty((b, 2, h, w), **f32), torch.empty((b, h, w), **f32)
+    acc = torch.empty((b * (h + 2) * (w + 2) * 5 + 4,), **f32)
+    warped, mask2, wdepth = torch.empty((b, 3, h, w), **f32), torch.empty((b, 1, h, w), **f32), torch.empty((b, 1, h, w), **f32)
+    check(_lib.load().tcx_warp_forward(_p(frame), _p(mask1), _p(depth), _p(mats), _p(flow), _p(tdepth), _p(acc), _p(warped),
+                                       _p(mask2), _p(wdepth), b, h, w, _stream()), "tcx_warp_forward")
+    return warped, mask2, wdepth, flow
