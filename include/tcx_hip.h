@@ -206,11 +206,18 @@ int tcx_cl_to_ncthw_frames(const void* x, float* y, int32_t N, int32_t C, int64_
  * frame [b,3,h,w], depth [b,1,h,w], mask1 [b,1,h,w] or null, all fp32 NCHW like the reference.
  * mats: fp32 [b,30] = K1^-1 (9) | rows of [R|t] of T2 T1^-1 (12) | K2 (9), prepared by the host (tiny inverses).
  * Outputs: flow [b,2,h,w], warped [b,3,h,w] in [-1,1] (-1 where empty), mask2 [b,1,h,w], wdepth [b,1,h,w].
- * Workspace: tdepth [b,h,w] and acc fp32 [b*(h+2)*(w+2)*5 + 4] (zeroed by the call on the stream).
+ * Workspace: tdepth [b,h,w] and acc fp32 [b*(h+2)*(w+2)*5 + b] (zeroed by the call on the stream).
+ * flags: TCX_WARP_PER_ITEM_MAX normalises the depth weight by each item's own max(log(1+depth)) instead of the max
+ * over the batch (:478-479) — one call then equals b reference calls with batch 1, which is how the reference renders
+ * a clip (demo.py:100-116 loops over frames).
  * Float atomics: matches the reference / oracle to ~1e-5, not bitwise. */
+#define TCX_WARP_PER_ITEM_MAX 1
+/* TCX_WARP_CLEAN_POINTS = forward_warp(mask=True): clean_points (:585-626) — the hole mask dilated by a 5x5 box
+ * (cv2.dilate, borders ignored); the frame is blanked to -1 there, mask2 = 1 - dilated holes; depth is not cleaned. */
+#define TCX_WARP_CLEAN_POINTS 2
 int tcx_warp_forward(const float* frame, const float* mask1, const float* depth, const float* mats,
                      float* flow, float* tdepth, float* acc, float* warped, float* mask2, float* wdepth,
-                     int32_t b, int32_t h, int32_t w, void* stream);
+                     int32_t b, int32_t h, int32_t w, int32_t flags, void* stream);
 
 #ifdef __cplusplus
 }

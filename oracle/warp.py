@@ -2,8 +2,7 @@
 (TEST INFRASTRUCTURE, see oracle/__init__.py).
 
 Follows reference models/utils.py: compute_transformed_points :350-421, bilinear_splatting :422-583,
-create_grid :626-634, forward_warp :220-293 (the `twice=False` branch; `clean_points` (cv2 dilate, `--mask`, off by
-default inference.py:49) is not on this path).  Pure torch, fp32, CPU.  Pinned by tests/golden/warp_tiny.safetensors
+create_grid :626-634, forward_warp :220-293 (the `twice=False` branch; `clean_points` :585-626 for mask=True).  Pure torch, fp32, CPU.  Pinned by tests/golden/warp_tiny.safetensors
 (generated from the reference's own Warper).
 """
 from __future__ import annotations
@@ -69,8 +68,19 @@ def bilinear_splat(frame: torch.Tensor, mask1: Optional[torch.Tensor], depth: to
     return out, hit.to(frame.dtype)
 
 
-def forward_warp(frame1, mask1, depth1, t1, t2, k1, k2=None):
-    """reference :220-293 (mask=False, twice=False) -> (warped_frame2, mask2, warped_depth2, flow12)."""
+def clean_points(warped: torch.Tensor, mask2: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """reference :585-626: holes (1 - mask2) dilated with cv2.dilate(ones(5,5)) — a 5x5 max filter whose border pixels
+    are ignored (cv2's default border value for dilate) — then frame01 * (1 - holes) back to [-1,1].  cv2 is absent
+    from this image: the dilation is restated from its documented semantics (parity unpinned for this sub-step); the
+    reference's float64 promotion (numpy /255.0) is kept."""
+    holes = (1 - mask2 >= 0.5).to(torch.float64)
+    holes = torch.nn.functional.max_pool2d(holes, 5, stride=1, padding=2)      # pads with -inf: border ignored
+    out = ((warped + 1.0) / 2.0) * (1 - holes)
+    return out * 2.0 - 1.0, 1 - holes[:, 0:1]
+
+
+def forward_warp(frame1, mask1, depth1, t1, t2, k1, k2=None, mask=False):
+    """reference :220-293 (twice=False) -> (warped_frame2, mask2, warped_depth2, flow12)."""
     pts = transformed_points(depth1, t1, t2, k1, k2)
     coords = pts[..., :2] / pts[..., 2:3]
     tdepth = pts[..., 2]
@@ -79,4 +89,6 @@ def forward_warp(frame1, mask1, depth1, t1, t2, k1, k2=None):
     flow = coords.permute(0, 3, 1, 2) - torch.stack([xs, ys], 0)[None].to(coords)
     warped, mask2 = bilinear_splat(frame1, mask1, tdepth, flow, True)
     wdepth, _ = bilinear_splat(tdepth[:, None], mask1, tdepth, flow, False)
+    if mask:
+        warped, mask2 = clean_points(warped, mask2)
     return warped, mask2, wdepth, flow

@@ -15,15 +15,17 @@ struct WarpParams {
     const float *frame, *mask1, *depth, *mats;
     float *flow, *tdepth, *acc, *warped, *mask2, *wdepth;
     unsigned* logmax;
-    int32_t b, h, w;
+    int32_t b, h, w, per_item, clean;
 };
 
 // mats[n] = { K1inv (9, row major), Rel (12: 3 x 4 rows of [R|t]), K2 (9) }
 __global__ __launch_bounds__(256) void warp_project_kernel(const WarpParams p) {
-    const int64_t total = (int64_t)p.b * p.h * p.w;
-    float lmax = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % p.w), y = (int)((i / p.w) % p.h), n = (int)(i / ((int64_t)p.w * p.h));
+    const int64_t hw = (int64_t)p.h * p.w, total = (int64_t)p.b * hw;
+    // block-uniform trip count: the wave reduction below needs every lane present
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += (int64_t)gridDim.x * blockDim.x) {
+        const bool valid = base + threadIdx.x < total;
+        const int64_t i = valid ? base + threadIdx.x : total - 1;
+        const int x = (int)(i % p.w), y = (int)((i / p.w) % p.h), n = (int)(i / hw);
         const float* m = p.mats + 30 * n;
         const float fx = (float)x, fy = (float)y, d = p.depth[i];
         float ray[3], cam[3], pr[3];
@@ -34,20 +36,27 @@ __global__ __launch_bounds__(256) void warp_project_kernel(const WarpParams p) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) pr[r] = m[21 + 3 * r] * cam[0] + m[21 + 3 * r + 1] * cam[1] + m[21 + 3 * r + 2] * cam[2];
         if (cam[2] <= 0.01f) pr[0] = pr[1] = pr[2] = 1000.0f;                  // behind the target camera (:403-417)
-        const int64_t hw = (int64_t)p.h * p.w, pix = i - (int64_t)n * hw;
-        p.flow[(2 * (int64_t)n) * hw + pix] = pr[0] / pr[2] - fx;
-        p.flow[(2 * (int64_t)n + 1) * hw + pix] = pr[1] / pr[2] - fy;
-        p.tdepth[i] = pr[2];
-        lmax = fmaxf(lmax, logf(1.0f + fminf(fmaxf(pr[2], 0.f), 1000.0f)));
-    }
+        if (valid) {
+            const int64_t pix = i - (int64_t)n * hw;
+            p.flow[(2 * (int64_t)n) * hw + pix] = pr[0] / pr[2] - fx;
+            p.flow[(2 * (int64_t)n + 1) * hw + pix] = pr[1] / pr[2] - fy;
+            p.tdepth[i] = pr[2];
+        }
+        // max of log(1+depth) over the batch (reference :478-479) or per item; non-negative floats order like their bits
+        float lmax = valid ? logf(1.0f + fminf(fmaxf(pr[2], 0.f), 1000.0f)) : 0.f;
+        const int slot = p.per_item ? n : 0;
+        if (__all(slot == __builtin_amdgcn_readfirstlane(slot))) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(p.logmax, __float_as_uint(lmax));   // non-negative floats order like their bits
+            for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+            if ((threadIdx.x & 63) == 0) atomicMax(p.logmax + slot, __float_as_uint(lmax));
+        } else {
+            atomicMax(p.logmax + slot, __float_as_uint(lmax));
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void warp_splat_kernel(const WarpParams p) {
     const int64_t hw = (int64_t)p.h * p.w, total = (int64_t)p.b * hw;
-    const float inv_logmax = 1.0f / __uint_as_float(*p.logmax);
     const int W2 = p.w + 2, H2 = p.h + 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % p.w), y = (int)((i / p.w) % p.h), n = (int)(i / hw);
@@ -62,7 +71,8 @@ __global__ __launch_bounds__(256) void warp_splat_kernel(const WarpParams p) {
         px = fminf(fmaxf(px, 0.f), lim_x);
         py = fminf(fmaxf(py, 0.f), lim_y);
         const float dfx = px - flx, dfy = py - fly, dcx = cex - px, dcy = cey - py;
-        const float dw = expf(logf(1.0f + fminf(fmaxf(td, 0.f), 1000.0f)) * inv_logmax * 50.0f);
+        const float logmax = __uint_as_float(p.logmax[p.per_item ? n : 0]);
+        const float dw = expf(logf(1.0f + fminf(fmaxf(td, 0.f), 1000.0f)) / logmax * 50.0f);
         const float base = (p.mask1 ? p.mask1[i] : 1.0f) / dw;
         const float v[4] = {p.frame[(3 * (int64_t)n) * hw + pix], p.frame[(3 * (int64_t)n + 1) * hw + pix],
                             p.frame[(3 * (int64_t)n + 2) * hw + pix], td};
@@ -90,13 +100,24 @@ __global__ __launch_bounds__(256) void warp_resolve_kernel(const WarpParams p) {
         const float* a = p.acc + (((int64_t)n * H2 + y + 1) * W2 + x + 1) * 5;
         const float wsum = a[4];
         const bool hit = wsum > 0.f;
+        bool keep = hit;
+        if (p.clean) {                                   // clean_points (:585-626): holes dilated by a 5x5 box
+            for (int dy = -2; dy <= 2; ++dy)
+                for (int dx = -2; dx <= 2; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w)
+                        keep = keep && (a[((int64_t)dy * W2 + dx) * 5 + 4] > 0.f);
+                }
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float o = hit ? a[c] / wsum : -1.0f;
-            p.warped[(3 * (int64_t)n + c) * hw + pix] = fminf(fmaxf(o, -1.0f), 1.0f);
+            o = fminf(fmaxf(o, -1.0f), 1.0f);
+            if (p.clean) o = ((o + 1.0f) / 2.0f) * (keep ? 1.0f : 0.0f) * 2.0f - 1.0f;
+            p.warped[(3 * (int64_t)n + c) * hw + pix] = o;
         }
-        p.wdepth[i] = hit ? a[3] / wsum : 0.0f;
-        p.mask2[i] = hit ? 1.0f : 0.0f;
+        p.wdepth[i] = hit ? a[3] / wsum : 0.0f;          // the depth map is not cleaned (:287-293)
+        p.mask2[i] = keep ? 1.0f : 0.0f;
     }
 }
 
@@ -109,15 +130,17 @@ inline unsigned wgrid(int64_t n) {
 
 extern "C" int tcx_warp_forward(const float* frame, const float* mask1, const float* depth, const float* mats,
                                 float* flow, float* tdepth, float* acc, float* warped, float* mask2, float* wdepth,
-                                int32_t b, int32_t h, int32_t w, void* stream) {
+                                int32_t b, int32_t h, int32_t w, int32_t flags, void* stream) {
     TCX_CHECK(frame && depth && mats && flow && tdepth && acc && warped && mask2 && wdepth, TCX_E_NULL, "tcx_warp_forward: null pointer");
     TCX_CHECK(b > 0 && h > 0 && w > 0, TCX_E_SHAPE, "tcx_warp_forward: empty shape");
     hipStream_t st = (hipStream_t)stream;
-    const size_t acc_bytes = sizeof(float) * ((size_t)b * (h + 2) * (w + 2) * 5 + 4);     // + one 16-byte slot: max log-depth
+    TCX_CHECK((flags & ~(TCX_WARP_PER_ITEM_MAX | TCX_WARP_CLEAN_POINTS)) == 0, TCX_E_SHAPE, "tcx_warp_forward: unknown flags 0x%x", flags);
+    const size_t acc_bytes = sizeof(float) * ((size_t)b * (h + 2) * (w + 2) * 5 + b);     // + b words: max log-depth
     hipError_t e = hipMemsetAsync(acc, 0, acc_bytes, st);
     if (e != hipSuccess) { tcx_set_error("tcx_warp_forward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     WarpParams p{frame, mask1, depth, mats, flow, tdepth, acc, warped, mask2, wdepth,
-                 reinterpret_cast<unsigned*>(acc + (size_t)b * (h + 2) * (w + 2) * 5), b, h, w};
+                 reinterpret_cast<unsigned*>(acc + (size_t)b * (h + 2) * (w + 2) * 5), b, h, w,
+                 (flags & TCX_WARP_PER_ITEM_MAX) ? 1 : 0, (flags & TCX_WARP_CLEAN_POINTS) ? 1 : 0};
     const int64_t total = (int64_t)b * h * w;
     hipLaunchKernelGGL(warp_project_kernel, dim3(wgrid(total)), dim3(256), 0, st, p);
     hipLaunchKernelGGL(warp_splat_kernel, dim3(wgrid(total)), dim3(256), 0, st, p);

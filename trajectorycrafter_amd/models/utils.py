@@ -1,7 +1,8 @@
 """MI355X-native `Warper` — the point-cloud render of reference models/utils.py:213-293.
 
-Only the path the reference's `inference.py` takes by default is built: `forward_warp(..., mask=False, twice=False)`
-(`--mask` is off by default, inference.py:49; `clean_points` needs cv2).  The 4x4 / 3x3 inverses are tiny host-side
+Built: `forward_warp(..., mask=False|True, twice=False)` — what demo.py calls (`--mask` selects `clean_points`, the
+5x5 dilation of the holes, done here inside the resolve kernel instead of a cv2 round trip through the host; with
+mask=True the reference returns float64 because of a numpy promotion, this returns fp32).  The 4x4 / 3x3 inverses are tiny host-side
 torch ops; projection, splatting (float atomics) and normalisation are HIP kernels (`tcx_warp_forward`)."""
 from __future__ import annotations
 
@@ -21,11 +22,13 @@ class Warper:
 
     def forward_warp(self, frame1: torch.Tensor, mask1: Optional[torch.Tensor], depth1: torch.Tensor,
                      transformation1: torch.Tensor, transformation2: torch.Tensor, intrinsic1: torch.Tensor,
-                     intrinsic2: Optional[torch.Tensor], mask=False, twice=False
+                     intrinsic2: Optional[torch.Tensor], mask=False, twice=False, per_frame: bool = False
                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-        """reference :220-293 -> (warped_frame2 [b,3,h,w] in [-1,1], mask2 [b,1,h,w], warped_depth2 [b,1,h,w], flow12 [b,2,h,w])."""
-        if mask or twice:
-            raise NotImplementedError("only forward_warp(mask=False, twice=False) — the reference's default path — is built")
+        """reference :220-293 -> (warped_frame2 [b,3,h,w] in [-1,1], mask2 [b,1,h,w], warped_depth2 [b,1,h,w], flow12 [b,2,h,w]).
+        per_frame=True (not in the reference): the b items are b independent batch-1 reference calls — the whole clip
+        of demo.py:100-116's per-frame loop in one launch."""
+        if twice:
+            raise NotImplementedError("forward_warp(twice=True) is not on the reference's inference path (demo.py passes twice=False)")
         if self.device.type != "cuda":
             raise TcxError("Warper: the HIP splat needs a GPU device (no CPU fallback; use oracle.warp on the CPU)")
         if self.resolution is not None:
@@ -42,4 +45,4 @@ class Warper:
         rel = torch.bmm(t2, torch.linalg.inv(t1))                                 # :365-367
         mats = torch.cat([torch.linalg.inv(k1).reshape(b, 9), rel[:, :3, :].reshape(b, 12), k2.reshape(b, 9)], dim=1).contiguous()
         return ops.warp_forward(frame1.to(**to).contiguous(), None if mask1 is None else mask1.to(**to).contiguous(),
-                                depth1.to(**to).contiguous(), mats)
+                                depth1.to(**to).contiguous(), mats, per_item_max=per_frame, clean_points=bool(mask))

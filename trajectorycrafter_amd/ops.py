@@ -337,9 +337,12 @@ def cl_to_frames(x: torch.Tensor, out: torch.Tensor, t_offset: int) -> None:
 
 
 # ----------------------------------------------------------------------------- point-cloud render
-def warp_forward(frame: torch.Tensor, mask1: Optional[torch.Tensor], depth: torch.Tensor, mats: torch.Tensor):
+def warp_forward(frame: torch.Tensor, mask1: Optional[torch.Tensor], depth: torch.Tensor, mats: torch.Tensor,
+                 per_item_max: bool = False, clean_points: bool = False):
     """frame [b,3,h,w], depth [b,1,h,w], mask1 [b,1,h,w] | None, mats [b,30] (all fp32, GPU, contiguous)
-    -> (warped [b,3,h,w], mask2 [b,1,h,w], warped_depth [b,1,h,w], flow [b,2,h,w])."""
+    -> (warped [b,3,h,w], mask2 [b,1,h,w], warped_depth [b,1,h,w], flow [b,2,h,w]).
+    per_item_max: each batch item is rendered as its own batch-1 reference call (TCX_WARP_PER_ITEM_MAX);
+    clean_points: forward_warp(mask=True) (TCX_WARP_CLEAN_POINTS)."""
     for n, t in (("frame", frame), ("depth", depth), ("mats", mats)) + ((("mask1", mask1),) if mask1 is not None else ()):
         _need(t, n, torch.float32)
         if not t.is_contiguous():
@@ -349,8 +352,8 @@ def warp_forward(frame: torch.Tensor, mask1: Optional[torch.Tensor], depth: torc
         raise TcxError("warp_forward: shape mismatch")
     f32 = dict(device=frame.device, dtype=torch.float32)
     flow, tdepth = torch.empty((b, 2, h, w), **f32), torch.empty((b, h, w), **f32)
-    acc = torch.empty((b * (h + 2) * (w + 2) * 5 + 4,), **f32)
+    acc = torch.empty((b * (h + 2) * (w + 2) * 5 + b,), **f32)
     warped, mask2, wdepth = torch.empty((b, 3, h, w), **f32), torch.empty((b, 1, h, w), **f32), torch.empty((b, 1, h, w), **f32)
     check(_lib.load().tcx_warp_forward(_p(frame), _p(mask1), _p(depth), _p(mats), _p(flow), _p(tdepth), _p(acc), _p(warped),
-                                       _p(mask2), _p(wdepth), b, h, w, _stream()), "tcx_warp_forward")
+                                       _p(mask2), _p(wdepth), b, h, w, (1 if per_item_max else 0) | (2 if clean_points else 0), _stream()), "tcx_warp_forward")
     return warped, mask2, wdepth, flow
