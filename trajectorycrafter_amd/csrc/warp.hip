@@ -8,6 +8,7 @@
 // Float atomics commute only up to rounding: results match the oracle to ~1e-5, not bitwise (the reference's own
 // index_put_ accumulate on a GPU has the same property).
 #include "tcx_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -19,75 +20,130 @@ struct WarpParams {
 };
 
 // mats[n] = { K1inv (9, row major), Rel (12: 3 x 4 rows of [R|t]), K2 (9) }
+// grid = (blocks per item, b): a block stays inside one item, so the max of log(1+depth) costs one atomic per block.
 __global__ __launch_bounds__(256) void warp_project_kernel(const WarpParams p) {
-    const int64_t hw = (int64_t)p.h * p.w, total = (int64_t)p.b * hw;
-    // block-uniform trip count: the wave reduction below needs every lane present
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += (int64_t)gridDim.x * blockDim.x) {
-        const bool valid = base + threadIdx.x < total;
-        const int64_t i = valid ? base + threadIdx.x : total - 1;
-        const int x = (int)(i % p.w), y = (int)((i / p.w) % p.h), n = (int)(i / hw);
-        const float* m = p.mats + 30 * n;
+    const int hw = p.h * p.w, n = blockIdx.y;
+    const float* m = p.mats + 30 * n;
+    float k[30];
+#pragma unroll
+    for (int j = 0; j < 30; ++j) k[j] = m[j];
+    float lmax = 0.f;
+    for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < hw; pix += gridDim.x * blockDim.x) {
+        const int x = pix % p.w, y = pix / p.w;
+        const int64_t i = (int64_t)n * hw + pix;
         const float fx = (float)x, fy = (float)y, d = p.depth[i];
         float ray[3], cam[3], pr[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) ray[r] = (m[3 * r] * fx + m[3 * r + 1] * fy + m[3 * r + 2]) * d;
+        for (int r = 0; r < 3; ++r) ray[r] = (k[3 * r] * fx + k[3 * r + 1] * fy + k[3 * r + 2]) * d;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) cam[r] = (m[9 + 4 * r] * ray[0] + m[9 + 4 * r + 1] * ray[1] + m[9 + 4 * r + 2] * ray[2]) + m[9 + 4 * r + 3];
+        for (int r = 0; r < 3; ++r) cam[r] = (k[9 + 4 * r] * ray[0] + k[9 + 4 * r + 1] * ray[1] + k[9 + 4 * r + 2] * ray[2]) + k[9 + 4 * r + 3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) pr[r] = m[21 + 3 * r] * cam[0] + m[21 + 3 * r + 1] * cam[1] + m[21 + 3 * r + 2] * cam[2];
+        for (int r = 0; r < 3; ++r) pr[r] = k[21 + 3 * r] * cam[0] + k[21 + 3 * r + 1] * cam[1] + k[21 + 3 * r + 2] * cam[2];
         if (cam[2] <= 0.01f) pr[0] = pr[1] = pr[2] = 1000.0f;                  // behind the target camera (:403-417)
-        if (valid) {
-            const int64_t pix = i - (int64_t)n * hw;
-            p.flow[(2 * (int64_t)n) * hw + pix] = pr[0] / pr[2] - fx;
-            p.flow[(2 * (int64_t)n + 1) * hw + pix] = pr[1] / pr[2] - fy;
-            p.tdepth[i] = pr[2];
-        }
-        // max of log(1+depth) over the batch (reference :478-479) or per item; non-negative floats order like their bits
-        float lmax = valid ? logf(1.0f + fminf(fmaxf(pr[2], 0.f), 1000.0f)) : 0.f;
-        const int slot = p.per_item ? n : 0;
-        if (__all(slot == __builtin_amdgcn_readfirstlane(slot))) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
-            if ((threadIdx.x & 63) == 0) atomicMax(p.logmax + slot, __float_as_uint(lmax));
-        } else {
-            atomicMax(p.logmax + slot, __float_as_uint(lmax));
-        }
+        p.flow[(2 * (int64_t)n) * hw + pix] = pr[0] / pr[2] - fx;
+        p.flow[(2 * (int64_t)n + 1) * hw + pix] = pr[1] / pr[2] - fy;
+        p.tdepth[i] = pr[2];
+        lmax = fmaxf(lmax, logf(1.0f + fminf(fmaxf(pr[2], 0.f), 1000.0f)));
     }
+    // max of log(1+depth) over the batch (reference :478-479) or per item; non-negative floats order like their bits
+    __shared__ float smax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = lmax;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(p.logmax + (p.per_item ? n : 0), __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))));
 }
 
+// Splat.  Global float atomics are the bound (one 4-byte add per lane-op at the memory side), and the four corners of
+// neighbouring source pixels land on the same target pixels — so a workgroup first bins its 32x32 source tile into an
+// LDS window (ds_add_f32) placed around where the tile's centre lands, then flushes the touched window pixels with one
+// global atomic per float: ~4x fewer global atomics for near-unit magnification.  Corners that fall outside the
+// window (strong magnification, depth edges, points pushed behind the camera) go straight to global memory.
+constexpr int kTile = 32, kWinX = 48, kWinY = 44;
+
 __global__ __launch_bounds__(256) void warp_splat_kernel(const WarpParams p) {
-    const int64_t hw = (int64_t)p.h * p.w, total = (int64_t)p.b * hw;
+    __shared__ float win[5][kWinY][kWinX];
+    __shared__ int org[2];
+    const int hw = p.h * p.w, n = blockIdx.z;
+    const int x0 = blockIdx.x * kTile, y0 = blockIdx.y * kTile;
     const int W2 = p.w + 2, H2 = p.h + 2;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % p.w), y = (int)((i / p.w) % p.h), n = (int)(i / hw);
-        const int64_t pix = i - (int64_t)n * hw;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float lim_x = (float)(p.w + 1), lim_y = (float)(p.h + 1);
+    const float logmax = __uint_as_float(p.logmax[p.per_item ? n : 0]);
+    for (int j = threadIdx.x; j < 5 * kWinY * kWinX; j += 256) (&win[0][0][0])[j] = 0.f;
+
+    float wgt[4][4], val[4][4];
+    int cix[4][2], ciy[4][2];
+    bool valid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        valid[j] = x0 + tx < p.w && y0 + ty + 8 * j < p.h;
+        const int x = min(x0 + tx, p.w - 1), y = min(y0 + ty + 8 * j, p.h - 1);   // ragged tiles: stand-ins, not splatted
+        const int pix = y * p.w + x;
+        const int64_t i = (int64_t)n * hw + pix;
         const float td = p.tdepth[i];
         float px = p.flow[(2 * (int64_t)n) * hw + pix] + (float)x + 1.0f;       // +1: border of the padded accumulator
         float py = p.flow[(2 * (int64_t)n + 1) * hw + pix] + (float)y + 1.0f;
-        const float lim_x = (float)(p.w + 1), lim_y = (float)(p.h + 1);
         // floor / ceil BEFORE clamping, each then clamped on its own (reference :455-476)
         const float flx = fminf(fmaxf(floorf(px), 0.f), lim_x), fly = fminf(fmaxf(floorf(py), 0.f), lim_y);
         const float cex = fminf(fmaxf(ceilf(px), 0.f), lim_x), cey = fminf(fmaxf(ceilf(py), 0.f), lim_y);
         px = fminf(fmaxf(px, 0.f), lim_x);
         py = fminf(fmaxf(py, 0.f), lim_y);
         const float dfx = px - flx, dfy = py - fly, dcx = cex - px, dcy = cey - py;
-        const float logmax = __uint_as_float(p.logmax[p.per_item ? n : 0]);
         const float dw = expf(logf(1.0f + fminf(fmaxf(td, 0.f), 1000.0f)) / logmax * 50.0f);
         const float base = (p.mask1 ? p.mask1[i] : 1.0f) / dw;
-        const float v[4] = {p.frame[(3 * (int64_t)n) * hw + pix], p.frame[(3 * (int64_t)n + 1) * hw + pix],
-                            p.frame[(3 * (int64_t)n + 2) * hw + pix], td};
-        const int ix[2] = {(int)flx, (int)cex}, iy[2] = {(int)fly, (int)cey};
+        val[j][0] = p.frame[(3 * (int64_t)n) * hw + pix];
+        val[j][1] = p.frame[(3 * (int64_t)n + 1) * hw + pix];
+        val[j][2] = p.frame[(3 * (int64_t)n + 2) * hw + pix];
+        val[j][3] = td;
+        cix[j][0] = (int)flx; cix[j][1] = (int)cex;
+        ciy[j][0] = (int)fly; ciy[j][1] = (int)cey;
         const float wx[2] = {1.0f - dfx, 1.0f - dcx}, wy[2] = {1.0f - dfy, 1.0f - dcy};
 #pragma unroll
         for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
-            for (int cx = 0; cx < 2; ++cx) {
-                const float wgt = wy[cy] * wx[cx] * base;
-                float* dst = p.acc + (((int64_t)n * H2 + iy[cy]) * W2 + ix[cx]) * 5;
+            for (int cx = 0; cx < 2; ++cx) wgt[j][2 * cy + cx] = wy[cy] * wx[cx] * base;
+        // window origin: where the tile's centre pixel lands, minus half a window
+        if (j == 2 && tx == 16 && ty == 0) {             // pixel (x0+16, y0+16), or the tile's last valid one
+            org[0] = cix[j][0] - kWinX / 2;
+            org[1] = ciy[j][0] - kWinY / 2;
+        }
+    }
+    __syncthreads();
+    const int ox = org[0], oy = org[1];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) atomicAdd(dst + c, v[c] * wgt);
-                atomicAdd(dst + 4, wgt);
+    for (int j = 0; j < 4; ++j) {
+        if (!valid[j]) continue;
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+                const float wg = wgt[j][2 * cy + cx];
+                const int gx = cix[j][cx], gy = ciy[j][cy];
+                const int lx = gx - ox, ly = gy - oy;
+                if ((unsigned)lx < (unsigned)kWinX && (unsigned)ly < (unsigned)kWinY) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) atomicAdd(&win[c][ly][lx], val[j][c] * wg);
+                    atomicAdd(&win[4][ly][lx], wg);
+                } else {
+                    float* dst = p.acc + (((int64_t)n * H2 + gy) * W2 + gx) * 5;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) atomicAdd(dst + c, val[j][c] * wg);
+                    atomicAdd(dst + 4, wg);
+                }
             }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < kWinY * kWinX; j += 256) {
+        const int ly = j / kWinX, lx = j - ly * kWinX;
+        const float wsum = win[4][ly][lx];
+        if (wsum != 0.f) {                               // only in-range corners were binned: origin + (lx, ly) is inside the accumulator
+            float* dst = p.acc + (((int64_t)n * H2 + (oy + ly)) * W2 + (ox + lx)) * 5;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) atomicAdd(dst + c, win[c][ly][lx]);
+            atomicAdd(dst + 4, wsum);
+        }
     }
 }
 
@@ -142,8 +198,12 @@ extern "C" int tcx_warp_forward(const float* frame, const float* mask1, const fl
                  reinterpret_cast<unsigned*>(acc + (size_t)b * (h + 2) * (w + 2) * 5), b, h, w,
                  (flags & TCX_WARP_PER_ITEM_MAX) ? 1 : 0, (flags & TCX_WARP_CLEAN_POINTS) ? 1 : 0};
     const int64_t total = (int64_t)b * h * w;
-    hipLaunchKernelGGL(warp_project_kernel, dim3(wgrid(total)), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(warp_splat_kernel, dim3(wgrid(total)), dim3(256), 0, st, p);
+    TCX_CHECK(b <= 65535 && (h + kTile - 1) / kTile <= 65535, TCX_E_SHAPE, "tcx_warp_forward: b=%d / h=%d exceed the grid limits", b, h);
+    const int64_t hw = (int64_t)h * w;
+    TCX_CHECK(hw < (1ll << 30), TCX_E_SHAPE, "tcx_warp_forward: h*w = %lld too large", (long long)hw);
+    const unsigned pblocks = (unsigned)std::min<int64_t>((hw + 255) / 256, std::max<int64_t>(1, 4096 / b));
+    hipLaunchKernelGGL(warp_project_kernel, dim3(pblocks, b), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(warp_splat_kernel, dim3((w + kTile - 1) / kTile, (h + kTile - 1) / kTile, b), dim3(256), 0, st, p);
     hipLaunchKernelGGL(warp_resolve_kernel, dim3(wgrid(total)), dim3(256), 0, st, p);
     TCX_LAUNCH_RET();
 }
