@@ -199,6 +199,23 @@ int tcx_ncthw_to_cl(const void* x, void* y, int32_t N, int32_t C, int64_t spatia
 int tcx_cl_to_ncthw_frames(const void* x, float* y, int32_t N, int32_t C, int64_t spatial, int64_t out_spatial_stride,
                            int64_t out_offset, void* stream);
 
+/* ---- f0: bf16 GEMM with fused epilogues — the Linear layers of the transformer -----------------
+ * y[M,N] = epilogue(x[M,K] . w[N,K]^T + bias[N]); bf16 operands, fp32 accumulation, bf16 result; w is a torch
+ * nn.Linear weight as stored ([out, in], K contiguous); bias bf16 [N] or null.
+ *   TCX_GEMM_BIAS           y = acc + bias                                  (to_q/k/v, to_out, proj, ff.net.2 ...)
+ *   TCX_GEMM_BIAS_GELU      y = gelu_tanh(acc + bias)                       (FeedForward net.0, crosstransformer3d.py:215-222)
+ *   TCX_GEMM_GATED_RESIDUAL y = res + gate[b(row)] * (acc + bias)           (:245-248, 261-264; res may alias y)
+ *       gate_t for rows with (row % rows_per_batch) < text_len, gate_v otherwise, batch b = row / rows_per_batch,
+ *       gate[b] = gate_x + b * gate_stride_b; both gates null -> gate = 1 (the plain residual of :833-837).
+ * Needs N % 256 == 0, K % 128 == 0, ldx % 8 == 0, ldy % 4 == 0; any M.  Uses 128 KiB of LDS per workgroup. */
+#define TCX_GEMM_BIAS 0
+#define TCX_GEMM_BIAS_GELU 1
+#define TCX_GEMM_GATED_RESIDUAL 2
+int tcx_gemm_bf16(const void* x, const void* w, const void* bias, void* y, int64_t M, int32_t N, int32_t K,
+                  int64_t ldx, int64_t ldy, int32_t epilogue, const void* res, int64_t ldres,
+                  const void* gate_v, const void* gate_t, int64_t gate_stride_b, int32_t rows_per_batch,
+                  int32_t text_len, void* stream);
+
 /* ---- f3: point-cloud render = forward warp by bilinear splatting, fp32 ---------------------------
  * One call = Warper.forward_warp(frame1, mask1, depth1, T1, T2, K1, K2, mask=False, twice=False) of the reference
  * (models/utils.py:220-293): compute_transformed_points (:350-421) then bilinear_splatting of the frame and of the

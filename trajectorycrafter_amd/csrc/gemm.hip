@@ -1,0 +1,307 @@
+// bf16 GEMM with fused epilogues for the transformer's Linear layers:
+//     Y[M,N] = epilogue( X[M,K] . W[N,K]^T + bias[N] )           fp32 accumulate, bf16 in / out
+// epilogues: bias | bias + GELU(tanh) | res + gate * (acc + bias)   (the gated residual of CogVideoXBlock,
+// reference models/crosstransformer3d.py:245-248, 261-264).
+//
+// Structure (MI355X / gfx950 only): 256 x 256 output tile per 512-thread workgroup, K step 64, 8 waves as 2 (M) x 4 (N),
+// each wave a 128 x 64 sub-tile = 8 x 4 accumulators of v_mfma_f32_16x16x32_bf16 (128 VGPRs).  One workgroup per CU
+// (128 KiB LDS = two K-tile buffers x four 16 KiB "half-tiles").
+//
+//  * Operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4), never through registers.  The LDS image is lane-
+//    linear per wave instruction (1 KiB = 8 rows x 128 B), so the bank swizzle is applied to the SOURCE address:
+//    16-byte slot s of row r holds k-slot s ^ ((r >> 1) & 7); ds_read_b128 fragment reads are then conflict-free
+//    for the instruction's 16-lane groups (MI355X_MICROARCH.md, LDS table).
+//  * A half-tile is what one QUADRANT of every wave needs: X half qm = rows {wr*128 + qm*64 + [0,64)} of both wave
+//    rows, W half qn = columns {wc*64 + qn*32 + [0,32)} of all four wave columns.  A K-tile is computed in four phases,
+//    one 64 x 32 quadrant each, order (0,0) (0,1) (1,1) (1,0): X half 0 is read in phase 0 only, W half 1 in phase 1,
+//    X half 1 in phase 2, W half 0 in phases 0 and 3 — so each half-tile can be re-staged one phase after its last read
+//    and exactly one half-tile is staged per phase.
+//  * The two wave rows run one barrier apart (wr = 1 takes one extra s_barrier before the loop, wr = 0 one after it):
+//    while one wave of a SIMD issues its 16 MFMAs the other reads fragments and issues the LDS-DMA.
+//  * Ordering, per phase and wave:  ds_reads ; stage (2 glds) ; [vmcnt(6) in phases 3 and 7] ; lgkmcnt(0) ; s_barrier ;
+//    16 MFMA ; s_barrier.  With L_p / M_p the load / MFMA segments and k_j the j-th barrier, wave row 0 runs L_p in
+//    (k_2p, k_2p+1) and wave row 1 in (k_2p+1, k_2p+2):
+//      WAR: reads of phase p have returned (lgkmcnt(0)) before k_2p+2 at the latest; the earliest stage of phase q is
+//           issued after k_2q  ->  re-staging in phase q >= p + 1 is safe.
+//      RAW: a wave's LDS-DMA is complete when ITS vmcnt says so; all waves pass their phase-w wait before k_2w+2, the
+//           earliest read of phase r is after k_2r  ->  data waited for in phase w is readable from phase w + 1.
+//    Stage order (E / O = even / odd K-tile buffer): ph0 W0->O(kt+1) | ph1 X0->E(kt+2) | ph2 W1->E | ph3 X1->E |
+//    ph4 W0->E | ph5 X0->O(kt+3) | ph6 W1->O | ph7 X1->O.  vmcnt(6) in phase 3 leaves the three newest half-tiles
+//    (ph1..3) in flight and retires everything up to ph0's W0->O: the odd tile is complete for phases 4-7; likewise
+//    phase 7 completes the even tile for the next iteration.  Never vmcnt(0) inside the loop.
+//  * XCD-aware, bijective block remap; within an XCD's chunk tiles are ordered 4 (M) x all (N) so the 32 workgroups
+//    sharing an L2 reuse each X tile 8x and each W tile 4x.
+//  * Rows >= M are loaded from row M-1 (valid memory) and masked at the store; N % 256 == 0 and K % 128 == 0 are
+//    required (every Linear of the 5B transformer except the 64-wide proj_out and the K=132 patch embedding).
+#include "tcx_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF = 128 * BK * 2;   // 16 KiB: 128 rows x 64 bf16
+constexpr int BUF = 4 * HALF;        // X0 X1 W0 W1
+constexpr int LDS_BYTES = 2 * BUF;
+constexpr int GM = 4;                // M-tiles per band of the tile order
+
+struct GemmParams {
+    const uint16_t *x, *w, *bias;
+    uint16_t* y;
+    const uint16_t *res, *gate_v, *gate_t;
+    int64_t M, ldx, ldy, ldres, gate_stride_b;
+    int32_t N, K, rows_per_batch, text_len, mt, nt;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {   // same formula as elementwise.hip (tcx_bias_gelu_tanh)
+    const float u = 0.7978845608028654f * __builtin_fmaf(0.044715f * x * x, x, x);
+    const float e = __expf(2.0f * u);
+    const float t = 1.0f - 2.0f / (1.0f + e);
+    return 0.5f * x * (1.0f + t);
+}
+
+#define TCX_SB() __builtin_amdgcn_sched_barrier(0)
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+
+    // ---- tile of this workgroup ----
+    const int t = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int band = t / (GM * p.nt), rr = t - band * (GM * p.nt);
+    const int gme = min(GM, p.mt - band * GM);
+    const int tm = band * GM + rr % gme, tn = rr / gme;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+    const int KT = p.K / BK;
+
+    // ---- staging addresses: wave `wid` writes the 1-KiB pieces 2*wid, 2*wid+1 of every half-tile ----
+    const uint16_t* px[2][2];
+    const uint16_t* pw[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int lr = (wid * 2 + j) * 8 + (lane >> 3);                 // row of the half-tile
+        const int ksl = (lane & 7) ^ ((lr >> 1) & 7);                   // source k-slot of LDS slot (lane & 7)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int64_t row = m0 + (lr >> 6) * 128 + q * 64 + (lr & 63);
+            row = row < p.M ? row : p.M - 1;
+            px[q][j] = p.x + row * p.ldx + ksl * 8;
+            const int col = n0 + (lr >> 5) * 64 + q * 32 + (lr & 31);
+            pw[q][j] = p.w + (int64_t)col * p.K + ksl * 8;
+        }
+    }
+    auto stage = [&](auto hsel, int buf, int kt) __attribute__((always_inline)) {
+        constexpr int H = decltype(hsel)::value;                        // 0 X0, 1 X1, 2 W0, 3 W1
+        kt = kt < KT ? kt : KT - 1;                                     // past the end: harmless re-load (keeps vmcnt counts)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint16_t* src = (H < 2 ? px[H & 1][j] : pw[H & 1][j]) + (int64_t)kt * BK;
+            char* dst = lds + buf * BUF + H * HALF + (wid * 2 + j) * 1024;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+        }
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    using H2 = std::integral_constant<int, 2>;
+    using H3 = std::integral_constant<int, 3>;
+
+    // ---- fragment read addresses ----
+    const int fi = lane & 15, fg = lane >> 4, fx = (fi >> 1) & 7;
+    const int xo0 = (fg ^ fx) * 16, xo1 = xo0 ^ 64;
+    const int ax = (wr * 64 + fi) * 128, aw = (wc * 32 + fi) * 128;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[4][2], wf[2][2];
+
+    auto read_x = [&](int buf, int qm) __attribute__((always_inline)) {
+        const char* base = lds + buf * BUF + qm * HALF + ax;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            xf[tt][0] = *reinterpret_cast<const bf16x8*>(base + tt * 2048 + xo0);
+            xf[tt][1] = *reinterpret_cast<const bf16x8*>(base + tt * 2048 + xo1);
+        }
+    };
+    auto read_w = [&](int buf, int qn) __attribute__((always_inline)) {
+        const char* base = lds + buf * BUF + (2 + qn) * HALF + aw;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            wf[u][0] = *reinterpret_cast<const bf16x8*>(base + u * 2048 + xo0);
+            wf[u][1] = *reinterpret_cast<const bf16x8*>(base + u * 2048 + xo1);
+        }
+    };
+    auto mfma_quadrant = [&](auto qmsel, auto qnsel) __attribute__((always_inline)) {
+        constexpr int QM = decltype(qmsel)::value, QN = decltype(qnsel)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[QM * 4 + tt][QN * 2 + u] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][ks], xf[tt][ks], acc[QM * 4 + tt][QN * 2 + u], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // one phase: P = 0..7 (P >> 2 = buffer being computed), kt2 = even K-tile of this iteration
+    auto phase = [&](auto psel, int kt2) __attribute__((always_inline)) {
+        constexpr int P = decltype(psel)::value, B = P >> 2, Q = P & 3;
+        if constexpr (Q == 0) { read_w(B, 0); TCX_SB(); read_x(B, 0); }
+        if constexpr (Q == 1) read_w(B, 1);
+        if constexpr (Q == 2) read_x(B, 1);
+        if constexpr (Q == 3) read_w(B, 0);
+        TCX_SB();
+        if constexpr (P == 0) stage(H2{}, 1, kt2 + 1);
+        if constexpr (P == 1) stage(H0{}, 0, kt2 + 2);
+        if constexpr (P == 2) stage(H3{}, 0, kt2 + 2);
+        if constexpr (P == 3) stage(H1{}, 0, kt2 + 2);
+        if constexpr (P == 4) stage(H2{}, 0, kt2 + 2);
+        if constexpr (P == 5) stage(H0{}, 1, kt2 + 3);
+        if constexpr (P == 6) stage(H3{}, 1, kt2 + 3);
+        if constexpr (P == 7) stage(H1{}, 1, kt2 + 3);
+        TCX_SB();
+        if constexpr (Q == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        TCX_SB();
+        if constexpr (Q == 0) mfma_quadrant(H0{}, H0{});
+        if constexpr (Q == 1) mfma_quadrant(H0{}, H1{});
+        if constexpr (Q == 2) mfma_quadrant(H1{}, H1{});
+        if constexpr (Q == 3) mfma_quadrant(H1{}, H0{});
+        TCX_SB();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        TCX_SB();
+    };
+
+    // ---- prologue: K-tile 0 complete, three half-tiles of K-tile 1 in flight ----
+    stage(H0{}, 0, 0);
+    stage(H1{}, 0, 0);
+    stage(H2{}, 0, 0);
+    stage(H3{}, 0, 0);
+    stage(H0{}, 1, 1);
+    stage(H3{}, 1, 1);
+    stage(H1{}, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wr == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs one barrier behind
+    TCX_SB();
+
+    for (int kt2 = 0; kt2 < KT; kt2 += 2) {
+        phase(std::integral_constant<int, 0>{}, kt2);
+        phase(std::integral_constant<int, 1>{}, kt2);
+        phase(std::integral_constant<int, 2>{}, kt2);
+        phase(std::integral_constant<int, 3>{}, kt2);
+        phase(std::integral_constant<int, 4>{}, kt2);
+        phase(std::integral_constant<int, 5>{}, kt2);
+        phase(std::integral_constant<int, 6>{}, kt2);
+        phase(std::integral_constant<int, 7>{}, kt2);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the trailing (unused) LDS-DMA must land before the LDS is released
+
+    // ---- epilogue: lane holds C[m = .. + fi][n = .. + 4 fg + 0..3] of each 16x16 tile ----
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int64_t m = m0 + wr * 128 + a * 16 + fi;
+        if (m >= p.M) continue;
+        const uint16_t* gate = nullptr;
+        if constexpr (EPI == 2) {
+            if (p.gate_v) {
+                const int64_t b = m / p.rows_per_batch;
+                const int rb = (int)(m - b * p.rows_per_batch);
+                gate = (rb < p.text_len ? p.gate_t : p.gate_v) + b * p.gate_stride_b;
+            }
+        }
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) {
+            const int n = n0 + wc * 64 + bq * 16 + fg * 4;
+            float v[4] = {acc[a][bq][0], acc[a][bq][1], acc[a][bq][2], acc[a][bq][3]};
+            if (p.bias) {
+                const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + n);
+                v[0] += bf16lo(bb[0]); v[1] += bf16hi(bb[0]); v[2] += bf16lo(bb[1]); v[3] += bf16hi(bb[1]);
+            }
+            if constexpr (EPI == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = gelu_tanh_f(v[j]);
+            }
+            if constexpr (EPI == 2) {
+                const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + m * p.ldres + n);
+                float r[4] = {bf16lo(rv[0]), bf16hi(rv[0]), bf16lo(rv[1]), bf16hi(rv[1])};
+                if (gate) {
+                    const u32x2 gv = *reinterpret_cast<const u32x2*>(gate + n);
+                    const float gg[4] = {bf16lo(gv[0]), bf16hi(gv[0]), bf16lo(gv[1]), bf16hi(gv[1])};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = r[j] + gg[j] * v[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = r[j] + v[j];
+                }
+            }
+            u32x2 o;
+            o[0] = pack_bf16(v[0], v[1]);
+            o[1] = pack_bf16(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(p.y + m * p.ldy + n) = o;
+        }
+    }
+}
+
+template <int EPI>
+int launch_gemm(const GemmParams& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) { tcx_set_error("tcx_gemm_bf16: cannot reserve %d bytes of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_kernel<EPI>, dim3((unsigned)(p.mt * p.nt)), dim3(512), LDS_BYTES, st, p);
+    TCX_LAUNCH_RET();
+}
+
+}  // namespace
+
+extern "C" int tcx_gemm_bf16(const void* x, const void* w, const void* bias, void* y, int64_t M, int32_t N, int32_t K,
+                             int64_t ldx, int64_t ldy, int32_t epilogue, const void* res, int64_t ldres,
+                             const void* gate_v, const void* gate_t, int64_t gate_stride_b, int32_t rows_per_batch,
+                             int32_t text_len, void* stream) {
+    TCX_CHECK(x && w && y, TCX_E_NULL, "tcx_gemm_bf16: null x / w / y");
+    TCX_CHECK(M > 0 && N > 0 && K > 0, TCX_E_SHAPE, "tcx_gemm_bf16: empty shape M=%lld N=%d K=%d", (long long)M, N, K);
+    TCX_CHECK(N % BN == 0 && K % (2 * BK) == 0, TCX_E_SHAPE, "tcx_gemm_bf16: needs N %% 256 == 0 and K %% 128 == 0 (N=%d K=%d)", N, K);
+    TCX_CHECK(ldx >= K && ldy >= N && ldx % 8 == 0 && ldy % 4 == 0, TCX_E_SHAPE, "tcx_gemm_bf16: bad leading dimensions ldx=%lld ldy=%lld", (long long)ldx, (long long)ldy);
+    TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(w) && tcx_aligned16(y) && tcx_aligned16(bias), TCX_E_ALIGN, "tcx_gemm_bf16: pointers must be 16-byte aligned");
+    TCX_CHECK(epilogue >= 0 && epilogue <= 2, TCX_E_SHAPE, "tcx_gemm_bf16: unknown epilogue %d", epilogue);
+    const int64_t mt = (M + BM - 1) / BM;
+    TCX_CHECK(mt * (N / BN) < (1ll << 31), TCX_E_SHAPE, "tcx_gemm_bf16: too many tiles");
+    GemmParams p{};
+    p.x = (const uint16_t*)x; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias; p.y = (uint16_t*)y;
+    p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldy = ldy; p.mt = (int32_t)mt; p.nt = N / BN;
+    if (epilogue == TCX_GEMM_GATED_RESIDUAL) {
+        TCX_CHECK(res, TCX_E_NULL, "tcx_gemm_bf16: the gated-residual epilogue needs res");
+        TCX_CHECK(ldres >= N && ldres % 4 == 0 && tcx_aligned16(res), TCX_E_SHAPE, "tcx_gemm_bf16: bad res layout");
+        TCX_CHECK((gate_v == nullptr) == (gate_t == nullptr), TCX_E_NULL, "tcx_gemm_bf16: give both gates or none");
+        if (gate_v) {
+            TCX_CHECK(rows_per_batch > 0 && text_len >= 0 && text_len <= rows_per_batch && M % rows_per_batch == 0 && gate_stride_b % 4 == 0,
+                      TCX_E_SHAPE, "tcx_gemm_bf16: bad gate geometry rows_per_batch=%d text_len=%d", rows_per_batch, text_len);
+            TCX_CHECK(tcx_aligned16(gate_v) && tcx_aligned16(gate_t), TCX_E_ALIGN, "tcx_gemm_bf16: gates must be 16-byte aligned");
+        }
+        p.res = (const uint16_t*)res; p.ldres = ldres; p.gate_v = (const uint16_t*)gate_v; p.gate_t = (const uint16_t*)gate_t;
+        p.gate_stride_b = gate_stride_b; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; p.text_len = text_len;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    switch (epilogue) {
+        case TCX_GEMM_BIAS: return launch_gemm<0>(p, st);
+        case TCX_GEMM_BIAS_GELU: return launch_gemm<1>(p, st);
+        default: return launch_gemm<2>(p, st);
+    }
+}
