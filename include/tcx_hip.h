@@ -207,14 +207,17 @@ int tcx_cl_to_ncthw_frames(const void* x, float* y, int32_t N, int32_t C, int64_
  *   TCX_GEMM_GATED_RESIDUAL y = res + gate[b(row)] * (acc + bias)           (:245-248, 261-264; res may alias y)
  *       gate_t for rows with (row % rows_per_batch) < text_len, gate_v otherwise, batch b = row / rows_per_batch,
  *       gate[b] = gate_x + b * gate_stride_b; both gates null -> gate = 1 (the plain residual of :833-837).
- * Needs N % 256 == 0, K % 128 == 0, ldx % 8 == 0, ldy % 4 == 0; any M.  Uses 128 KiB of LDS per workgroup. */
+ * x rows are uniformly strided (ldx).  With rows_per_batch > 0, y and res are [B, rows_per_batch, N] views: row m =
+ * (b, r) lives at y + b * y_stride_b + r * ldy (a row range of the joint text+video buffer); with 0 they are flat.
+ * Needs N % 8 == 0, K % 128 == 0, ldx % 8 == 0, ldy % 4 == 0; any M.  256 x 256 output tiles (ragged edges are
+ * masked), 128 KiB of LDS per workgroup. */
 #define TCX_GEMM_BIAS 0
 #define TCX_GEMM_BIAS_GELU 1
 #define TCX_GEMM_GATED_RESIDUAL 2
 int tcx_gemm_bf16(const void* x, const void* w, const void* bias, void* y, int64_t M, int32_t N, int32_t K,
-                  int64_t ldx, int64_t ldy, int32_t epilogue, const void* res, int64_t ldres,
-                  const void* gate_v, const void* gate_t, int64_t gate_stride_b, int32_t rows_per_batch,
-                  int32_t text_len, void* stream);
+                  int64_t ldx, int64_t ldy, int64_t y_stride_b, int32_t epilogue, const void* res, int64_t ldres,
+                  int64_t res_stride_b, const void* gate_v, const void* gate_t, int64_t gate_stride_b,
+                  int32_t rows_per_batch, int32_t text_len, void* stream);
 
 /* ---- f3: point-cloud render = forward warp by bilinear splatting, fp32 ---------------------------
  * One call = Warper.forward_warp(frame1, mask1, depth1, T1, T2, K1, K2, mask=False, twice=False) of the reference

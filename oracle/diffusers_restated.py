@@ -185,7 +185,7 @@ def cogvideox_attention(p: Prec, sd: dict, prefix: str, hidden, encoder, heads: 
         q, k = p.R(q), p.R(k)                                # reference: unscaled q, softmax(q k^T / sqrt(dh))
         o = sdpa(p, q, k, v, scale=dh ** -0.5)
     o = p.R(o).transpose(1, 2).reshape(B, S, D)              # contract: attention output
-    o = p.linear(o, sd[prefix + "to_out.0.weight"], sd.get(prefix + "to_out.0.bias"))
+    o = p.linear_fused(o, sd[prefix + "to_out.0.weight"], sd.get(prefix + "to_out.0.bias"))   # consumed by the gated residual
     return o[:, text_len:], o[:, :text_len]
 
 
@@ -194,7 +194,7 @@ def feed_forward(p: Prec, sd: dict, prefix: str, x):
     y = F.linear(x.float(), p.param(sd[prefix + "net.0.proj.weight"]), p.param(sd[prefix + "net.0.proj.bias"]))
     y = p.r(y)                                               # reference rounds the GEMM output first
     y = p.R(F.gelu(y, approximate="tanh"))                   # contract: fused bias+GELU output
-    return p.linear(y, sd[prefix + "net.2.weight"], sd[prefix + "net.2.bias"])
+    return p.linear_fused(y, sd[prefix + "net.2.weight"], sd[prefix + "net.2.bias"])      # consumed by the gated residual
 
 
 # ---------------------------------------------------------------------------

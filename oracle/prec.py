@@ -45,6 +45,11 @@ class Prec:
     def linear(self, x, w, b=None):
         return self.R(F.linear(x.float(), self.param(w), self.param(b)))
 
+    def linear_fused(self, x, w, b=None):
+        """A Linear whose result the HIP path keeps in registers for a fused epilogue (`res + gate * y` in
+        tcx_gemm_bf16): rounded only where the reference's eager execution materialises it."""
+        return self.r(F.linear(x.float(), self.param(w), self.param(b)))
+
     def layer_norm(self, x, w, b, eps, contract_point: bool = False):
         y = F.layer_norm(x.float(), (x.shape[-1],), self.param(w), self.param(b), eps)
         return self.R(y) if contract_point else self.r(y)

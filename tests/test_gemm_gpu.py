@@ -51,7 +51,8 @@ def _check(got, want, scale=1.0):
     assert float((g == w).float().mean()) > 0.99
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 256), (1, 256, 128), (777, 768, 384), (452, 3072, 4096)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 256), (1, 256, 128), (777, 768, 384), (452, 3072, 4096),
+                                   (300, 128, 128), (64, 384, 512), (100, 520, 128), (2, 64, 3072)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_matches_oracle(ops, M, N, K, epi):
     g = torch.Generator().manual_seed(M * 7 + N + K + epi)
@@ -67,7 +68,7 @@ def test_gemm_matches_oracle(ops, M, N, K, epi):
             B = 2 if M % 2 == 0 else 3
             rpb = M // B
             gv, gt = torch.randn(B, N, generator=g).to(BF), torch.randn(B, N, generator=g).to(BF)
-            kw.update(gate_v=gv.cuda(), gate_t=gt.cuda(), rows_per_batch=rpb, text_len=rpb // 3)
+            kw.update(gate_v=gv.cuda(), gate_t=gt.cuda(), text_len=rpb // 3)
             okw.update(gv=gv, gt=gt, rpb=rpb, tl=rpb // 3)
     got = ops.gemm_bf16(x.cuda(), w.cuda(), b.cuda(), epilogue=epi, **kw)
     _check(got, _oracle(x, w, b, epi, **okw), scale=2.0)
@@ -86,21 +87,29 @@ def test_gemm_strided_views_in_place_and_no_bias(ops):
     want = _oracle(x, w, None, 2, res=h.view(-1, N), gv=gv, gt=gt, rpb=S, tl=40)
     hd, modd = h.cuda(), mod.cuda()
     out = ops.gemm_bf16(wide.cuda()[:, K:2 * K], w.cuda(), None, epilogue=2, res=hd, gate_v=modd[:, 2 * N:3 * N],
-                        gate_t=modd[:, 5 * N:6 * N], rows_per_batch=S, text_len=40, out=hd)
+                        gate_t=modd[:, 5 * N:6 * N], text_len=40, out=hd)
     assert out.data_ptr() == hd.data_ptr()
     _check(hd.view(-1, N), want, scale=2.0)
+    # a row range of a joint buffer (video rows 40.. of every batch item), no gates: the cross-attention residual
+    joint = torch.randn(B, 40 + S, N, generator=g).to(BF)
+    want2 = _oracle(x, w, None, 2, res=joint[:, 40:].reshape(-1, N))
+    jd = joint.cuda()
+    vid = jd[:, 40:]
+    ops.gemm_bf16(wide.cuda()[:, K:2 * K], w.cuda(), None, epilogue=2, res=vid, out=vid)
+    _check(jd[:, 40:].reshape(-1, N), want2, scale=2.0)
+    assert torch.equal(jd[:, :40].cpu(), joint[:, :40])              # text rows untouched
 
 
 def test_gemm_rejects_bad_shapes(ops):
     from trajectorycrafter_amd._lib import TcxError
     x = torch.zeros(8, 128, dtype=BF, device="cuda")
     with pytest.raises(TcxError):
-        ops.gemm_bf16(x, torch.zeros(64, 128, dtype=BF, device="cuda"))           # N % 256
+        ops.gemm_bf16(x, torch.zeros(60, 128, dtype=BF, device="cuda"))           # N % 8
     with pytest.raises(TcxError):
         ops.gemm_bf16(x[:, :64], torch.zeros(256, 64, dtype=BF, device="cuda"))     # K % 128
     with pytest.raises(TcxError):
         ops.gemm_bf16(x, torch.zeros(256, 128, dtype=BF, device="cuda"), epilogue=2)   # no res
-    assert ops.gemm_supported(3072, 12288) and not ops.gemm_supported(64, 3072) and not ops.gemm_supported(3072, 132)
+    assert ops.gemm_supported(3072, 12288) and ops.gemm_supported(64, 3072) and not ops.gemm_supported(3072, 132)
 
 
 def test_gemm_full_size_repeatable_and_linear(ops):

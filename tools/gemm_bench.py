@@ -42,8 +42,7 @@ for name, N, K, epi in (("qkv", 9216, 3072, 0), ("attn_out+gate", 3072, 3072, 2)
         def lib():
             y = F.linear(x, w, b)
             ops.gated_residual_(h.view(2, M // 2, N), y.view(2, M // 2, N), gate[:, :N], gate[:, N:], 226)
-        mine = lambda: ops.gemm_bf16(x, w, b, epilogue=2, res=h, gate_v=gate[:, :N], gate_t=gate[:, N:], rows_per_batch=M // 2,
-                                     text_len=226, out=h)
+        mine = lambda: ops.gemm_bf16(x, w, b, epilogue=2, res=h, gate_v=gate[:, :N], gate_t=gate[:, N:], text_len=226, out=h)
     tl, tm = timeit(lib), timeit(mine)
     print(f"{name:14s} M={M} N={N:5d} K={K:5d}: library {tl:7.3f} ms ({fl / tl / 1e9:6.0f} TF)   tcx_gemm {tm:7.3f} ms ({fl / tm / 1e9:6.0f} TF)", flush=True)
     del x, w, b, h

@@ -31,8 +31,8 @@
 //    phase 7 completes the even tile for the next iteration.  Never vmcnt(0) inside the loop.
 //  * XCD-aware, bijective block remap; within an XCD's chunk tiles are ordered 4 (M) x all (N) so the 32 workgroups
 //    sharing an L2 reuse each X tile 8x and each W tile 4x.
-//  * Rows >= M are loaded from row M-1 (valid memory) and masked at the store; N % 256 == 0 and K % 128 == 0 are
-//    required (every Linear of the 5B transformer except the 64-wide proj_out and the K=132 patch embedding).
+//  * Rows >= M / columns >= N are loaded from the last valid row of X / W and masked at the store; N % 8 == 0 and
+//    K % 128 == 0 are required (every Linear of the 5B transformer except the K = 132 patch embedding).
 #include "tcx_common.h"
 #include <type_traits>
 
@@ -48,7 +48,7 @@ struct GemmParams {
     const uint16_t *x, *w, *bias;
     uint16_t* y;
     const uint16_t *res, *gate_v, *gate_t;
-    int64_t M, ldx, ldy, ldres, gate_stride_b;
+    int64_t M, ldx, ldy, ldres, gate_stride_b, y_stride_b, res_stride_b;
     int32_t N, K, rows_per_batch, text_len, mt, nt;
 };
 
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
             int64_t row = m0 + (lr >> 6) * 128 + q * 64 + (lr & 63);
             row = row < p.M ? row : p.M - 1;
             px[q][j] = p.x + row * p.ldx + ksl * 8;
-            const int col = n0 + (lr >> 5) * 64 + q * 32 + (lr & 31);
+            int col = n0 + (lr >> 5) * 64 + q * 32 + (lr & 31);
+            col = col < p.N ? col : p.N - 1;
             pw[q][j] = p.w + (int64_t)col * p.K + ksl * 8;
         }
     }
@@ -216,17 +217,20 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
     for (int a = 0; a < 8; ++a) {
         const int64_t m = m0 + wr * 128 + a * 16 + fi;
         if (m >= p.M) continue;
+        // rows_per_batch > 0: row m = (batch b, row rb); y / res / gates are addressed per batch (strided row ranges)
+        int64_t b = 0, rb = m;
+        if (p.rows_per_batch > 0) { b = m / p.rows_per_batch; rb = m - b * p.rows_per_batch; }
+        uint16_t* yrow = p.y + b * p.y_stride_b + rb * p.ldy;
+        const uint16_t* rrow = nullptr;
         const uint16_t* gate = nullptr;
         if constexpr (EPI == 2) {
-            if (p.gate_v) {
-                const int64_t b = m / p.rows_per_batch;
-                const int rb = (int)(m - b * p.rows_per_batch);
-                gate = (rb < p.text_len ? p.gate_t : p.gate_v) + b * p.gate_stride_b;
-            }
+            rrow = p.res + b * p.res_stride_b + rb * p.ldres;
+            if (p.gate_v) gate = (rb < p.text_len ? p.gate_t : p.gate_v) + b * p.gate_stride_b;
         }
 #pragma unroll
         for (int bq = 0; bq < 4; ++bq) {
             const int n = n0 + wc * 64 + bq * 16 + fg * 4;
+            if (n >= p.N) continue;                      // N % 4 == 0: a lane's four columns are in or out together
             float v[4] = {acc[a][bq][0], acc[a][bq][1], acc[a][bq][2], acc[a][bq][3]};
             if (p.bias) {
                 const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + n);
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
                 for (int j = 0; j < 4; ++j) v[j] = gelu_tanh_f(v[j]);
             }
             if constexpr (EPI == 2) {
-                const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + m * p.ldres + n);
+                const u32x2 rv = *reinterpret_cast<const u32x2*>(rrow + n);
                 float r[4] = {bf16lo(rv[0]), bf16hi(rv[0]), bf16lo(rv[1]), bf16hi(rv[1])};
                 if (gate) {
                     const u32x2 gv = *reinterpret_cast<const u32x2*>(gate + n);
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
             u32x2 o;
             o[0] = pack_bf16(v[0], v[1]);
             o[1] = pack_bf16(v[2], v[3]);
-            *reinterpret_cast<u32x2*>(p.y + m * p.ldy + n) = o;
+            *reinterpret_cast<u32x2*>(yrow + n) = o;
         }
     }
 }
@@ -272,31 +276,37 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
 }  // namespace
 
 extern "C" int tcx_gemm_bf16(const void* x, const void* w, const void* bias, void* y, int64_t M, int32_t N, int32_t K,
-                             int64_t ldx, int64_t ldy, int32_t epilogue, const void* res, int64_t ldres,
-                             const void* gate_v, const void* gate_t, int64_t gate_stride_b, int32_t rows_per_batch,
-                             int32_t text_len, void* stream) {
+                             int64_t ldx, int64_t ldy, int64_t y_stride_b, int32_t epilogue, const void* res, int64_t ldres,
+                             int64_t res_stride_b, const void* gate_v, const void* gate_t, int64_t gate_stride_b,
+                             int32_t rows_per_batch, int32_t text_len, void* stream) {
     TCX_CHECK(x && w && y, TCX_E_NULL, "tcx_gemm_bf16: null x / w / y");
     TCX_CHECK(M > 0 && N > 0 && K > 0, TCX_E_SHAPE, "tcx_gemm_bf16: empty shape M=%lld N=%d K=%d", (long long)M, N, K);
-    TCX_CHECK(N % BN == 0 && K % (2 * BK) == 0, TCX_E_SHAPE, "tcx_gemm_bf16: needs N %% 256 == 0 and K %% 128 == 0 (N=%d K=%d)", N, K);
+    TCX_CHECK(N % 8 == 0 && K % (2 * BK) == 0, TCX_E_SHAPE, "tcx_gemm_bf16: needs N %% 8 == 0 and K %% 128 == 0 (N=%d K=%d)", N, K);
     TCX_CHECK(ldx >= K && ldy >= N && ldx % 8 == 0 && ldy % 4 == 0, TCX_E_SHAPE, "tcx_gemm_bf16: bad leading dimensions ldx=%lld ldy=%lld", (long long)ldx, (long long)ldy);
     TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(w) && tcx_aligned16(y) && tcx_aligned16(bias), TCX_E_ALIGN, "tcx_gemm_bf16: pointers must be 16-byte aligned");
     TCX_CHECK(epilogue >= 0 && epilogue <= 2, TCX_E_SHAPE, "tcx_gemm_bf16: unknown epilogue %d", epilogue);
     const int64_t mt = (M + BM - 1) / BM;
-    TCX_CHECK(mt * (N / BN) < (1ll << 31), TCX_E_SHAPE, "tcx_gemm_bf16: too many tiles");
+    const int32_t ntile = (N + BN - 1) / BN;
+    TCX_CHECK(mt * ntile < (1ll << 31), TCX_E_SHAPE, "tcx_gemm_bf16: too many tiles");
     GemmParams p{};
     p.x = (const uint16_t*)x; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias; p.y = (uint16_t*)y;
-    p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldy = ldy; p.mt = (int32_t)mt; p.nt = N / BN;
+    p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldy = ldy; p.mt = (int32_t)mt; p.nt = ntile;
+    TCX_CHECK(rows_per_batch >= 0 && (rows_per_batch == 0 || M % rows_per_batch == 0), TCX_E_SHAPE,
+              "tcx_gemm_bf16: M=%lld is not a multiple of rows_per_batch=%d", (long long)M, rows_per_batch);
+    TCX_CHECK(rows_per_batch > 0 || y_stride_b == 0, TCX_E_SHAPE, "tcx_gemm_bf16: y_stride_b needs rows_per_batch");
+    TCX_CHECK(y_stride_b % 4 == 0 && res_stride_b % 4 == 0, TCX_E_ALIGN, "tcx_gemm_bf16: batch strides must be multiples of 4 elements");
+    p.rows_per_batch = rows_per_batch; p.y_stride_b = rows_per_batch > 0 ? y_stride_b : 0;
     if (epilogue == TCX_GEMM_GATED_RESIDUAL) {
         TCX_CHECK(res, TCX_E_NULL, "tcx_gemm_bf16: the gated-residual epilogue needs res");
         TCX_CHECK(ldres >= N && ldres % 4 == 0 && tcx_aligned16(res), TCX_E_SHAPE, "tcx_gemm_bf16: bad res layout");
         TCX_CHECK((gate_v == nullptr) == (gate_t == nullptr), TCX_E_NULL, "tcx_gemm_bf16: give both gates or none");
         if (gate_v) {
-            TCX_CHECK(rows_per_batch > 0 && text_len >= 0 && text_len <= rows_per_batch && M % rows_per_batch == 0 && gate_stride_b % 4 == 0,
+            TCX_CHECK(rows_per_batch > 0 && text_len >= 0 && text_len <= rows_per_batch && gate_stride_b % 4 == 0,
                       TCX_E_SHAPE, "tcx_gemm_bf16: bad gate geometry rows_per_batch=%d text_len=%d", rows_per_batch, text_len);
             TCX_CHECK(tcx_aligned16(gate_v) && tcx_aligned16(gate_t), TCX_E_ALIGN, "tcx_gemm_bf16: gates must be 16-byte aligned");
         }
         p.res = (const uint16_t*)res; p.ldres = ldres; p.gate_v = (const uint16_t*)gate_v; p.gate_t = (const uint16_t*)gate_t;
-        p.gate_stride_b = gate_stride_b; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; p.text_len = text_len;
+        p.gate_stride_b = gate_stride_b; p.text_len = text_len; p.res_stride_b = rows_per_batch > 0 ? res_stride_b : 0;
     }
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {

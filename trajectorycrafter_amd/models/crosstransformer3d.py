@@ -2,7 +2,7 @@
 
 Same class names, constructor kwargs, `.config`, sub-module / parameter names (state-dict keys) and
 `forward()` signature as the reference (:403-492, :711-721); the arithmetic runs on hand-written
-HIP kernels (libtcx_hip.so, see include/tcx_hip.h) plus hipBLASLt GEMMs through `F.linear`.
+HIP kernels (libtcx_hip.so, see include/tcx_hip.h), the Linear layers included (`tcx_gemm_bf16`, fused epilogues).
 
 Design differences from the reference (same maths, different data movement):
   * text and video tokens live in ONE joint `[B, 226 + T*h*w, D]` bf16 buffer for the whole forward
@@ -34,7 +34,6 @@ from ..config import ConfigMixin, ModelMixin, load_state_dict_from_dir, register
 
 BF16 = torch.bfloat16
 LOG2E = 1.4426950408889634
-_HAS_FUSED_GELU = hasattr(torch, "_addmm_activation")     # library GEMM with a fused bias+GELU(tanh) epilogue
 
 
 @dataclass
@@ -42,9 +41,24 @@ class Transformer2DModelOutput:
     sample: torch.Tensor
 
 
-def _linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Plain library GEMM (hipBLASLt via torch), bf16 in / fp32 accumulate / bf16 out."""
-    return F.linear(x, w, b)
+def _linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, epilogue: int = ops.GEMM_BIAS,
+            res: Optional[torch.Tensor] = None, gate_v: Optional[torch.Tensor] = None,
+            gate_t: Optional[torch.Tensor] = None, text_len: int = 0) -> torch.Tensor:
+    """y = epilogue(x @ w.T + b), bf16 in / fp32 accumulate / bf16 out, on the hand-written MFMA kernel
+    (`tcx_gemm_bf16`) for every shape it takes (N % 8 == 0, K % 128 == 0: all Linears of the blocks, embeddings and
+    modulations of the 5B model).  GEMM_GATED_RESIDUAL updates `res` in place and returns it.
+    Other shapes (the K = 132 patch embedding; narrow test configurations) are a plain library GEMM followed by the
+    stand-alone HIP epilogue kernels."""
+    if ops.gemm_supported(w.shape[0], w.shape[1]):
+        if epilogue == ops.GEMM_GATED_RESIDUAL:
+            return ops.gemm_bf16(x, w, b, epilogue=epilogue, res=res, gate_v=gate_v, gate_t=gate_t, text_len=text_len, out=res)
+        return ops.gemm_bf16(x, w, b, epilogue=epilogue)
+    if epilogue == ops.GEMM_BIAS_GELU:
+        return ops.bias_gelu_tanh_(F.linear(x, w), b)
+    y = F.linear(x, w, b)
+    if epilogue == ops.GEMM_GATED_RESIDUAL:
+        return ops.gated_residual_(res, y.view(res.shape), gate_v, gate_t, text_len)
+    return y
 
 
 def _require_hip(t: torch.Tensor, what: str) -> None:
@@ -168,8 +182,11 @@ class Attention(nn.Module):
         return self._fused[1], self._fused[2]
 
     def forward(self, x_joint: torch.Tensor, text_len: int,
-                image_rotary_emb: Optional[Tuple[torch.Tensor, torch.Tensor]]) -> torch.Tensor:
-        """Joint text+video self-attention on [B,S,D] (text first) -> to_out projection [B,S,D]."""
+                image_rotary_emb: Optional[Tuple[torch.Tensor, torch.Tensor]],
+                residual: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
+                e_gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Joint text+video self-attention on [B,S,D] (text first) -> to_out projection [B,S,D].
+        residual given: `residual += gate * to_out(attn)` in the projection's epilogue (reference :245-248), returned."""
         B, S, D = x_joint.shape
         H, dh = self.heads, self.dim_head
         w, b = self._fused_qkv()
@@ -181,6 +198,9 @@ class Attention(nn.Module):
         ksq = ops.qk_layernorm_rope(q, k, self.norm_q.weight, self.norm_q.bias, self.norm_k.weight, self.norm_k.bias,
                                     cos, sin, text_len, self.eps, q_scale=dh ** -0.5 * LOG2E, want_k_sqmax=True)
         o = ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq)          # [B,S,H,dh] contiguous
+        if residual is not None:
+            return _linear(o.view(B, S, D), self.to_out[0].weight, self.to_out[0].bias, ops.GEMM_GATED_RESIDUAL,
+                           res=residual, gate_v=gate, gate_t=e_gate, text_len=text_len)
         return _linear(o.view(B, S, D), self.to_out[0].weight, self.to_out[0].bias)
 
 
@@ -205,14 +225,14 @@ class FeedForward(nn.Module):
             layers.append(nn.Dropout(dropout))
         self.net = nn.ModuleList(layers)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        w1, b1 = self.net[0].proj.weight, self.net[0].proj.bias
-        if _HAS_FUSED_GELU and b1 is not None:
-            # bias + GELU(tanh) in the GEMM's own epilogue (hipBLASLt): one rounding, no extra 1.7 GB HBM pass
-            h = torch._addmm_activation(b1, x.reshape(-1, x.shape[-1]), w1.t(), use_gelu=True).view(*x.shape[:-1], w1.shape[0])
-        else:
-            h = _linear(x, w1)                                                # bias folded into the hand-written epilogue kernel
-            ops.bias_gelu_tanh_(h, b1)
+    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
+                e_gate: Optional[torch.Tensor] = None, text_len: int = 0) -> torch.Tensor:
+        """net.0 with bias + GELU(tanh) in the GEMM epilogue (one rounding, no separate 1.7 GB activation pass); with
+        `residual`, net.2 ends in `residual += gate * y` (reference :261-264) and `residual` is returned."""
+        h = _linear(x, self.net[0].proj.weight, self.net[0].proj.bias, ops.GEMM_BIAS_GELU)
+        if residual is not None:
+            return _linear(h, self.net[2].weight, self.net[2].bias, ops.GEMM_GATED_RESIDUAL, res=residual, gate_v=gate,
+                           gate_t=e_gate, text_len=text_len)
         return _linear(h, self.net[2].weight, self.net[2].bias)
 
 
@@ -236,11 +256,9 @@ class CogVideoXBlock(nn.Module):
     def forward_joint(self, x_joint: torch.Tensor, text_len: int, silu_temb: torch.Tensor,
                       image_rotary_emb: Optional[Tuple[torch.Tensor, torch.Tensor]]) -> torch.Tensor:
         n, gate, e_gate = self.norm1.modulate(x_joint, silu_temb, text_len)          # :234-236
-        a = self.attn1(n, text_len, image_rotary_emb)                                 # :239-243
-        ops.gated_residual_(x_joint, a, gate, e_gate, text_len)                       # :245-248
+        self.attn1(n, text_len, image_rotary_emb, residual=x_joint, gate=gate, e_gate=e_gate)    # :239-248
         n, gate, e_gate = self.norm2.modulate(x_joint, silu_temb, text_len)           # :251-253
-        f = self.ff(n)                                                                # :256-259
-        ops.gated_residual_(x_joint, f, gate, e_gate, text_len)                       # :261-264
+        self.ff(n, residual=x_joint, gate=gate, e_gate=e_gate, text_len=text_len)     # :256-264
         return x_joint
 
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, temb: torch.Tensor,
@@ -274,8 +292,9 @@ class PerceiverCrossAttention(nn.Module):
         self.to_kv = nn.Linear(dim if kv_dim is None else kv_dim, inner_dim * 2, bias=False)
         self.to_out = nn.Linear(inner_dim, dim, bias=False)
 
-    def forward(self, x: torch.Tensor, latents: torch.Tensor) -> torch.Tensor:
-        """x: reference tokens [B,Sr,D]; latents: video tokens [B,Sv,D] (may be a strided row range)."""
+    def forward(self, x: torch.Tensor, latents: torch.Tensor, add_to_latents: bool = False) -> torch.Tensor:
+        """x: reference tokens [B,Sr,D]; latents: video tokens [B,Sv,D] (may be a strided row range).
+        add_to_latents: `latents += to_out(...)` in the projection's epilogue (the caller's residual, reference :833-837)."""
         _require_hip(latents, "PerceiverCrossAttention")
         B, Sv, _ = latents.shape
         H, dh = self.heads, self.dim_head
@@ -288,6 +307,8 @@ class PerceiverCrossAttention(nn.Module):
         q = ops.scale_bf16(q, s, out=q)                                                              # :392 (q * scale)
         k = ops.scale_bf16(k.contiguous(), s)                                                        # :392 (k * scale)
         o = ops.attn_fwd(q.view(B, Sv, H, dh), k.view(B, -1, H, dh), v.view(B, -1, H, dh), 1.0)      # :392-395
+        if add_to_latents:
+            return _linear(o.view(B, Sv, H * dh), self.to_out.weight, None, ops.GEMM_GATED_RESIDUAL, res=latents)
         return _linear(o.view(B, Sv, H * dh), self.to_out.weight)                                   # :397-398
 
 
@@ -482,8 +503,7 @@ class CrossTransformer3DModel(ModelMixin, ConfigMixin):
         for i, block in enumerate(self.transformer_blocks):
             block.forward_joint(x, text_len, silu_emb, rotary)
             if self.is_train_cross and i % self.cross_attn_interval == 0:
-                ca = self.perceiver_cross_attention[ca_idx](cross_hidden_states, video)
-                ops.gated_residual_(video, ca)                                      # :833-837
+                self.perceiver_cross_attention[ca_idx](cross_hidden_states, video, add_to_latents=True)   # :833-837
                 ca_idx += 1
 
         # norm_final is row-wise: the reference's cat(text, video) -> LN -> drop text (:848-850) == LN(video rows)

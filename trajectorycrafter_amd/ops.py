@@ -290,59 +290,79 @@ GEMM_BIAS, GEMM_BIAS_GELU, GEMM_GATED_RESIDUAL = 0, 1, 2
 
 
 def gemm_supported(N: int, K: int) -> bool:
-    """Shapes `tcx_gemm_bf16` takes (256-wide output tiles, two 64-deep K steps per iteration)."""
-    return N % 256 == 0 and K % 128 == 0
+    """Shapes `tcx_gemm_bf16` takes (8-byte stores, two 64-deep K steps per iteration)."""
+    return N % 8 == 0 and K % 128 == 0
+
+
+def _gemm_rows(t: torch.Tensor, name: str, N: int, M: int) -> Tuple[int, int, int]:
+    """A [.., N] tensor of M rows -> (rows_per_batch, ld, stride_b).  rows_per_batch = 0: all rows share one stride
+    (flat); otherwise a [B, rows, N] view whose batch stride is free (a row range of the joint text+video buffer)."""
+    if t.dim() < 1 or t.shape[-1] != N or t.stride(-1) != 1 or t.numel() != M * N:
+        raise TcxError(f"gemm_bf16: {name} must be [.., {N}] with {M} rows and a contiguous last dimension, got {tuple(t.shape)} / {t.stride()}")
+    dims = [(n_, st) for n_, st in zip(t.shape[:-1], t.stride()[:-1]) if n_ != 1]
+    if not dims:
+        return 0, N, 0
+    ld = dims[-1][1]
+    if all(dims[i][1] == dims[i + 1][1] * dims[i + 1][0] for i in range(len(dims) - 1)):
+        return 0, ld, 0
+    if len(dims) == 2:
+        return dims[1][0], ld, dims[0][1]
+    raise TcxError(f"gemm_bf16: {name} rows are neither uniformly strided nor a [B, rows, N] view: {tuple(t.shape)} / {t.stride()}")
 
 
 def gemm_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = GEMM_BIAS,
               res: Optional[torch.Tensor] = None, gate_v: Optional[torch.Tensor] = None,
-              gate_t: Optional[torch.Tensor] = None, rows_per_batch: int = 0, text_len: int = 0,
+              gate_t: Optional[torch.Tensor] = None, text_len: int = 0,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = epilogue(x @ w.T + bias) on the hand-written 256x256 MFMA kernel (include/tcx_hip.h, tcx_gemm_bf16).
     x [..., K] bf16 (rows uniformly strided, K contiguous), w [N, K] bf16 contiguous.
-    GEMM_GATED_RESIDUAL: y = res + gate * (acc + bias); res [..., N]; gate_v / gate_t [B, N] views (unit inner stride,
-    common batch stride) or both None; rows b*rows_per_batch + r with r < text_len take gate_t.  `out` may be `res`."""
+    GEMM_GATED_RESIDUAL: y = res + gate * (acc + bias); res / out [.., N] or [B, rows, N] views with a free batch stride
+    (a row range of the joint buffer); gate_v / gate_t [B, N] views (unit inner stride, common batch stride) or both
+    None; rows r < text_len of every batch item take gate_t.  `out` may be `res` (in place)."""
     _need(x, "x"); _need(w, "w")
-    N, K = w.shape
-    if x.shape[-1] != K or not w.is_contiguous():
+    if w.dim() != 2 or not w.is_contiguous() or x.shape[-1] != w.shape[1]:
         raise TcxError(f"gemm_bf16: x {tuple(x.shape)} does not match w {tuple(w.shape)} (contiguous [N,K])")
-    x2 = x.reshape(-1, K)
-    if x2.stride(1) != 1:
-        raise TcxError("gemm_bf16: the K dimension of x must be contiguous")
-    M = x2.shape[0]
-    ldx = x2.stride(0) if M > 1 else K
+    N, K = w.shape
+    M = x.numel() // K
+    xr, ldx, _ = _gemm_rows(x, "x", K, M)
+    if xr:
+        raise TcxError("gemm_bf16: the rows of x must be uniformly strided")
     if out is None:
         out = torch.empty((*x.shape[:-1], N), device=x.device, dtype=torch.bfloat16)
     _need(out, "out")
-    o2 = out.view(-1, N)
-    if o2.shape[0] != M or o2.stride(1) != 1:
-        raise TcxError("gemm_bf16: out must be [.., N] with a contiguous last dimension")
-    ldy = o2.stride(0) if M > 1 else N
+    rpb, ldy, ysb = _gemm_rows(out, "out", N, M)
     if bias is not None:
         _need(bias, "bias")
         if bias.numel() != N or not bias.is_contiguous():
             raise TcxError("gemm_bf16: bias must be a contiguous [N] tensor")
-    r2, ldres, gsb = None, 0, 0
+    ldres, rsb, gsb = 0, 0, 0
     if epilogue == GEMM_GATED_RESIDUAL:
         if res is None:
             raise TcxError("gemm_bf16: the gated-residual epilogue needs res")
         _need(res, "res")
-        r2 = res.view(-1, N)
-        if r2.shape[0] != M or r2.stride(1) != 1:
-            raise TcxError("gemm_bf16: res must be [.., N] with a contiguous last dimension")
-        ldres = r2.stride(0) if M > 1 else N
+        rpb_r, ldres, rsb = _gemm_rows(res, "res", N, M)
         if (gate_v is None) != (gate_t is None):
             raise TcxError("gemm_bf16: give both gates or none")
+        rpb_g = 0
         if gate_v is not None:
             for n_, g in (("gate_v", gate_v), ("gate_t", gate_t)):
                 _need(g, n_)
                 if g.dim() != 2 or g.shape[1] != N or g.stride(1) != 1:
                     raise TcxError(f"gemm_bf16: {n_} must be a [B, N] view with unit inner stride")
-            if gate_v.stride(0) != gate_t.stride(0) or gate_v.shape[0] * rows_per_batch != M:
+            B = gate_v.shape[0]
+            if gate_v.stride(0) != gate_t.stride(0) or gate_t.shape[0] != B or M % B != 0:
                 raise TcxError("gemm_bf16: gate batch geometry does not match x")
-            gsb = gate_v.stride(0)
-    check(_lib.load().tcx_gemm_bf16(_p(x2), _p(w), _p(bias), _p(o2), M, N, K, ldx, ldy, int(epilogue), _p(r2), ldres,
-                                    _p(gate_v), _p(gate_t), gsb, int(rows_per_batch), int(text_len), _stream()), "tcx_gemm_bf16")
+            rpb_g, gsb = M // B, gate_v.stride(0)
+        want = {r for r in (rpb, rpb_r, rpb_g) if r}
+        if len(want) > 1:
+            raise TcxError(f"gemm_bf16: out / res / gates disagree on rows per batch: {sorted(want)}")
+        rpb = want.pop() if want else 0
+        if rpb and not rsb:
+            rsb = rpb * ldres                                            # flat res seen as [B, rpb, N]
+    if rpb and not ysb:
+        ysb = rpb * ldy
+    check(_lib.load().tcx_gemm_bf16(_p(x), _p(w), _p(bias), _p(out), M, N, K, ldx, ldy, ysb, int(epilogue), _p(res), ldres, rsb,
+                                    _p(gate_v), _p(gate_t), gsb, int(rpb), int(text_len), _stream()), "tcx_gemm_bf16")
     return out
 
 
