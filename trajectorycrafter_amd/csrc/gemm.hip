@@ -55,11 +55,13 @@ struct GemmParams {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-__device__ __forceinline__ float gelu_tanh_f(float x) {   // same formula as elementwise.hip (tcx_bias_gelu_tanh)
-    const float u = 0.7978845608028654f * __builtin_fmaf(0.044715f * x * x, x, x);
-    const float e = __expf(2.0f * u);
-    const float t = 1.0f - 2.0f / (1.0f + e);
-    return 0.5f * x * (1.0f + t);
+// gelu_tanh(x) = 0.5 x (1 + tanh(u)) = x / (1 + 2^(-2 u log2 e)),  u = sqrt(2/pi) (x + 0.044715 x^3): one exp2 and one
+// reciprocal (1 ulp each; the result is rounded to bf16, 2^-9 relative) instead of an exp, an IEEE division and a dozen
+// VALU ops per element of the 128-per-lane epilogue.  2^+inf -> x / inf = -0 for x -> -inf, 2^-inf -> x.
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float c = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+    const float e = __builtin_amdgcn_exp2f(c * __builtin_fmaf(0.044715f * x * x, x, x));
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 #define TCX_SB() __builtin_amdgcn_sched_barrier(0)
