@@ -192,7 +192,9 @@ def test_attn_fwd_rejects_bad_arguments(ops):
         ops.attn_fwd(q, q, q, 1.0)
 
 
-@pytest.mark.parametrize("C,rows,text_len", [(3072, 37, 5), (128, 50, 10), (2048, 9, 0), (256, 70, 70)])
+@pytest.mark.parametrize("C,rows,text_len", [(3072, 37, 5), (128, 50, 10), (2048, 9, 0), (256, 70, 70),
+                                              # >= 4096 rows: the row-looping kernel (parameters in registers)
+                                              (3072, 2101, 226), (1024, 2050, 0), (2048, 2049, 2049), (520, 2060, 3)])
 def test_layernorm_modulate(ops, C, rows, text_len):
     g = torch.Generator().manual_seed(C)
     B = 2
@@ -215,15 +217,15 @@ def test_layernorm_modulate(ops, C, rows, text_len):
 def test_layernorm_modulate_strided_video_rows(ops):
     """video rows of the joint [B, text+video, C] buffer (batch stride != rows*C)."""
     g = torch.Generator().manual_seed(3)
-    B, S, C, tl = 2, 40, 256, 8
-    x = bf(torch.randn(B, S, C, generator=g))
-    gamma, beta = bf(torch.randn(C, generator=g)), bf(torch.randn(C, generator=g))
-    ref = F.layer_norm(x[:, tl:].float(), (C,), gamma.float(), beta.float(), 1e-5)
-    y = ops.layernorm_modulate(dev(x)[:, tl:], dev(gamma), dev(beta), 1e-5)
-    assert_bf16_close(y, ref)
+    for B, S, C, tl in ((2, 40, 256, 8), (2, 2100, 512, 50)):          # second case: row-looping kernel
+        x = bf(torch.randn(B, S, C, generator=g))
+        gamma, beta = bf(torch.randn(C, generator=g)), bf(torch.randn(C, generator=g))
+        ref = F.layer_norm(x[:, tl:].float(), (C,), gamma.float(), beta.float(), 1e-5)
+        y = ops.layernorm_modulate(dev(x)[:, tl:], dev(gamma), dev(beta), 1e-5)
+        assert_bf16_close(y, ref)
 
 
-@pytest.mark.parametrize("B,S,H,text_len", [(2, 50, 2, 10), (1, 33, 48, 7), (1, 20, 3, 0)])
+@pytest.mark.parametrize("B,S,H,text_len", [(2, 50, 2, 10), (1, 33, 48, 7), (1, 20, 3, 0), (2, 77, 48, 9), (1, 300, 48, 0)])
 def test_qk_layernorm_rope(ops, B, S, H, text_len):
     g = torch.Generator().manual_seed(S)
     D = 64

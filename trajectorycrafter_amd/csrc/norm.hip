@@ -86,6 +86,104 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const LnParams p) {
     }
 }
 
+// Row-looping variant for large inputs: the per-row kernel above issues four parameter loads (gamma, beta, scale, shift)
+// for every load of x, and its loads die with the row.  Here a wave keeps its slices of the four parameter vectors in
+// registers (raw bf16), walks RPW rows of one segment (batch item x {text, video}: one modulation) and has the next row's
+// loads in flight while it reduces and writes the current one.  Same arithmetic, same order.
+constexpr int kLnRowsPerWave = 8;
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_modulate_rows_kernel(const LnParams p) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y >> 1, vid = blockIdx.y & 1;
+    const int seg0 = vid ? p.text_len : 0, seg1 = vid ? p.rows : p.text_len;
+    const int r0 = seg0 + (int)blockIdx.x * (4 * kLnRowsPerWave) + wv;     // this wave: r0, r0 + 4, ...
+    if (r0 >= seg1) return;
+    const int nchunk = p.C >> 3;
+    const uint16_t* sh = vid ? p.shift_v : p.shift_t;
+    const uint16_t* sc = vid ? p.scale_v : p.scale_t;
+    if (sh) sh += (int64_t)b * p.msb;
+    if (sc) sc += (int64_t)b * p.msb;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    u32x4 pg[NCH], pb[NCH], ps[NCH], pt[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = j * 64 + lane;
+        const bool ok = ch < nchunk;
+        pg[j] = (ok && p.gamma) ? *reinterpret_cast<const u32x4*>(p.gamma + 8 * ch) : zero4;
+        pb[j] = (ok && p.beta) ? *reinterpret_cast<const u32x4*>(p.beta + 8 * ch) : zero4;
+        ps[j] = (ok && sc) ? *reinterpret_cast<const u32x4*>(sc + 8 * ch) : zero4;
+        pt[j] = (ok && sh) ? *reinterpret_cast<const u32x4*>(sh + 8 * ch) : zero4;
+    }
+    const uint16_t* xb = p.x + (int64_t)b * p.xsb;
+    uint16_t* yb = p.y + (int64_t)b * p.ysb;
+    u32x4 raw[NCH], nraw[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = j * 64 + lane;
+        raw[j] = ch < nchunk ? *reinterpret_cast<const u32x4*>(xb + (int64_t)r0 * p.C + 8 * ch) : zero4;
+    }
+    const float invC = 1.0f / (float)p.C;
+    for (int i = 0; i < kLnRowsPerWave; ++i) {
+        const int r = r0 + 4 * i;
+        if (r >= seg1) break;
+        const bool more = i + 1 < kLnRowsPerWave && r + 4 < seg1;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = j * 64 + lane;
+            nraw[j] = (more && ch < nchunk) ? *reinterpret_cast<const u32x4*>(xb + (int64_t)(r + 4) * p.C + 8 * ch) : zero4;
+        }
+        // x and the parameters stay packed (raw bf16) in registers and are unpacked where used: holding them as floats
+        // (or letting the compiler hoist the parameter unpack out of the row loop) costs 200+ VGPRs and the occupancy
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            float v[8];
+            unpack8(raw[j], v);                          // chunks past the row are zero: they add nothing to the sums
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += v[e];
+        }
+        const float mean = wave_sum(sum) * invC;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (j * 64 + lane < nchunk) {
+                float v[8];
+                unpack8(raw[j], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[e] - mean;
+                    sq += d * d;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) * invC + p.eps);
+        uint16_t* yr = yb + (int64_t)r * p.C;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = j * 64 + lane;
+            if (ch < nchunk) {
+                asm volatile("" : "+v"(pg[j]), "+v"(pb[j]), "+v"(ps[j]), "+v"(pt[j]));   // keep the unpack inside the loop
+                float v[8], g[8], be[8], s1[8], s2[8], out[8];
+                unpack8(raw[j], v);
+                unpack8(pg[j], g); unpack8(pb[j], be); unpack8(ps[j], s1); unpack8(pt[j], s2);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = (v[e] - mean) * rstd;
+                    if (p.gamma) t *= g[e];
+                    if (p.beta) t += be[e];
+                    if (sc) t *= (1.0f + s1[e]);
+                    if (sh) t += s2[e];
+                    out[e] = t;
+                }
+                *reinterpret_cast<u32x4*>(yr + 8 * ch) = pack8(out);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) raw[j] = nraw[j];
+    }
+}
+
 struct QkParams {
     uint16_t *q, *k;
     int32_t B, S, H;
@@ -175,6 +273,122 @@ __global__ __launch_bounds__(256) void qk_ln_rope_kernel(const QkParams p) {
     }
 }
 
+// Token-per-wave variant for H = 8 * NI heads (the 5B model: NI = 6).  The kernel above reloads the token's cos / sin
+// slice and the four LayerNorm parameter slices for every head vector: 112 B requested per 16-B payload.  Here lane
+// (hs = lane >> 3, sub = lane & 7) owns elements 8 sub .. 8 sub + 7 of heads hs, hs + 8, ... of BOTH q and k of one token:
+// cos / sin are loaded once per token, gamma / beta once per wave, the 2 * NI row chunks of the next token are in flight
+// while the current one is normalised, and max |k|^2 is kept per head across the wave's tokens: one atomic per head
+// per wave instead of one per head vector.  Same arithmetic, same order as the kernel above.
+constexpr int kQkTokensPerWave = 8;
+
+template <int NI>
+__global__ __launch_bounds__(256) void qk_ln_rope_tok_kernel(const QkParams p) {
+    const int lane = threadIdx.x & 63, sub = lane & 7, hs = lane >> 3;
+    const int b = blockIdx.y;
+    const int s0 = ((int)blockIdx.x * 4 + (threadIdx.x >> 6)) * kQkTokensPerWave;
+    if (s0 >= p.S) return;
+    const int s1 = min(s0 + kQkTokensPerWave, p.S);
+    uint16_t* qb = p.q + (int64_t)b * p.sb + 8 * sub;
+    uint16_t* kb = p.k + (int64_t)b * p.sb + 8 * sub;
+    const u32x4 rgq = *reinterpret_cast<const u32x4*>(p.gq + 8 * sub), rbq = *reinterpret_cast<const u32x4*>(p.bq + 8 * sub);
+    const u32x4 rgk = *reinterpret_cast<const u32x4*>(p.gk + 8 * sub), rbk = *reinterpret_cast<const u32x4*>(p.bk + 8 * sub);
+    float kmax[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) kmax[i] = 0.f;
+    u32x4 rq[NI], rk[NI], nq[NI], nk[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int64_t off = (int64_t)s0 * p.ss + (int64_t)(8 * i + hs) * p.sh;
+        rq[i] = *reinterpret_cast<const u32x4*>(qb + off);
+        rk[i] = *reinterpret_cast<const u32x4*>(kb + off);
+    }
+    for (int s = s0; s < s1; ++s) {
+        const bool more = s + 1 < s1;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int64_t off = (int64_t)(more ? s + 1 : s) * p.ss + (int64_t)(8 * i + hs) * p.sh;
+            nq[i] = *reinterpret_cast<const u32x4*>(qb + off);
+            nk[i] = *reinterpret_cast<const u32x4*>(kb + off);
+        }
+        const bool rot = p.cos && s >= p.text_len;
+        float cs[8], sn[8];
+        if (rot) {
+            const int64_t ro = (int64_t)(s - p.text_len) * 64 + 8 * sub;
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.cos + ro), c1 = *reinterpret_cast<const f32x4*>(p.cos + ro + 4);
+            const f32x4 z0 = *reinterpret_cast<const f32x4*>(p.sin + ro), z1 = *reinterpret_cast<const f32x4*>(p.sin + ro + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cs[e] = c0[e]; cs[4 + e] = c1[e]; sn[e] = z0[e]; sn[4 + e] = z1[e]; }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                float x[8], g[8], be[8], y[8];
+                unpack8(which ? rk[i] : rq[i], x);
+                unpack8(which ? rgk : rgq, g);
+                unpack8(which ? rbk : rbq, be);
+                float sum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += x[e];
+                sum += __shfl_xor(sum, 1, 64);
+                sum += __shfl_xor(sum, 2, 64);
+                sum += __shfl_xor(sum, 4, 64);
+                const float mean = sum * (1.0f / 64.0f);
+                float sq = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = x[e] - mean;
+                    sq += d * d;
+                }
+                sq += __shfl_xor(sq, 1, 64);
+                sq += __shfl_xor(sq, 2, 64);
+                sq += __shfl_xor(sq, 4, 64);
+                const float rstd = rsqrtf(sq * (1.0f / 64.0f) + p.eps);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = (x[e] - mean) * rstd * g[e] + be[e];
+                if (rot) {
+                    float z[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {   // adjacent pairs (2e, 2e+1): rot = (-x_imag, x_real)
+                        z[2 * e] = y[2 * e] * cs[2 * e] - y[2 * e + 1] * sn[2 * e];
+                        z[2 * e + 1] = y[2 * e + 1] * cs[2 * e + 1] + y[2 * e] * sn[2 * e + 1];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = z[e];
+                }
+                if (!which) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] *= p.q_scale;
+                }
+                const u32x4 packed = pack8(y);
+                const int64_t off = (int64_t)s * p.ss + (int64_t)(8 * i + hs) * p.sh;
+                *reinterpret_cast<u32x4*>((which ? kb : qb) + off) = packed;
+                if (which && p.k_sqmax) {           // |k|^2 of the ROUNDED key
+                    float r[8];
+                    unpack8(packed, r);
+                    float ss = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(r[e], r[e], ss);
+                    ss += __shfl_xor(ss, 1, 64);
+                    ss += __shfl_xor(ss, 2, 64);
+                    ss += __shfl_xor(ss, 4, 64);
+                    kmax[i] = fmaxf(kmax[i], ss);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { rq[i] = nq[i]; rk[i] = nk[i]; }
+    }
+    if (p.k_sqmax && sub == 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            unsigned* dst = reinterpret_cast<unsigned*>(p.k_sqmax + (int64_t)b * p.H + 8 * i + hs);
+            const unsigned bits = __float_as_uint(kmax[i]);           // non-negative floats order like their bit patterns
+            if (bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int tcx_layernorm_modulate(const void* x, void* y, int32_t B, int32_t rows, int32_t C,
@@ -198,6 +412,16 @@ extern "C" int tcx_layernorm_modulate(const void* x, void* y, int32_t B, int32_t
     dim3 grid((unsigned)((total + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const int nch = (C / 8 + 63) / 64;
+    if (total >= 4096 && nch <= 6 && B <= 32767) {       // large inputs: row-looping kernel, parameters in registers
+        const int tl = (shift_t || scale_t) ? text_len : 0;   // no text modulation: one segment per batch item
+        p.text_len = tl;
+        const int seg = tl > rows - tl ? tl : rows - tl, per_block = 4 * kLnRowsPerWave;
+        dim3 g2((unsigned)((seg + per_block - 1) / per_block), (unsigned)(2 * B));
+        if (nch <= 2) hipLaunchKernelGGL(ln_modulate_rows_kernel<2>, g2, block, 0, st, p);
+        else if (nch <= 4) hipLaunchKernelGGL(ln_modulate_rows_kernel<4>, g2, block, 0, st, p);
+        else hipLaunchKernelGGL(ln_modulate_rows_kernel<6>, g2, block, 0, st, p);
+        TCX_LAUNCH_RET();
+    }
     if (nch <= 1) hipLaunchKernelGGL(ln_modulate_kernel<1>, grid, block, 0, st, p);
     else if (nch <= 2) hipLaunchKernelGGL(ln_modulate_kernel<2>, grid, block, 0, st, p);
     else if (nch <= 4) hipLaunchKernelGGL(ln_modulate_kernel<4>, grid, block, 0, st, p);
@@ -225,6 +449,12 @@ extern "C" int tcx_qk_layernorm_rope(void* q, void* k, int32_t B, int32_t S, int
     if (k_sqmax) {
         hipError_t me = hipMemsetAsync(k_sqmax, 0, sizeof(float) * (size_t)B * H, (hipStream_t)stream);
         if (me != hipSuccess) { tcx_set_error("tcx_qk_layernorm_rope: memset failed: %s", hipGetErrorString(me)); return (int)me; }
+    }
+    if (H == 48 && B <= 65535) {                         // the 5B model's head count: token-per-wave kernel
+        const int per_block = 4 * kQkTokensPerWave;
+        hipLaunchKernelGGL(qk_ln_rope_tok_kernel<6>, dim3((unsigned)((S + per_block - 1) / per_block), (unsigned)B), dim3(256), 0,
+                           (hipStream_t)stream, p);
+        TCX_LAUNCH_RET();
     }
     const int64_t nblk = (p.nvec + 31) / 32;
     TCX_CHECK(nblk < (1ll << 31), TCX_E_SHAPE, "tcx_qk_layernorm_rope: grid too large");
