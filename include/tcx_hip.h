@@ -122,13 +122,14 @@ int tcx_silu_bf16(const void* x, void* y, int64_t n, void* stream);
 /* ---- K8: patchify / unpatchify -------------------------------------------------------------------
  * patchify: gathers [B,F,C,H,W] (optionally the channel-concat of two tensors a:[.,Ca,.,.] and
  * b:[.,Cb,.,.]) into the im2col matrix [B*F*(H/p)*(W/p), (Ca+Cb)*p*p] (column order c,py,px =
- * Conv2d weight.flatten(1)) so the patch embedding is one GEMM.
+ * Conv2d weight.flatten(1)) so the patch embedding is one GEMM.  k_stride (0 = dense) >= (Ca+Cb)*p*p is the row
+ * length of `out`, zero-filled past the data: tcx_gemm_bf16 wants K % 128 == 0 (132 -> 256 for the 5B model).
  * Replaces: torch.concat + nn.Conv2d(k=p, stride=p) + flatten/transpose in
  *   CogVideoXPatchEmbed.forward / RefPatchEmbed.forward (models/crosstransformer3d.py:736, 78-87,
  *   120-135).
  * unpatchify: [B, F*(H/p)*(W/p), Cout*p*p] -> [B,F,Cout,H,W] (models/crosstransformer3d.py:863-867). */
 int tcx_patchify(const void* a, const void* b, void* out, int32_t B, int32_t F, int32_t Ca, int32_t Cb,
-                 int32_t H, int32_t W, int32_t p, void* stream);
+                 int32_t H, int32_t W, int32_t p, int32_t k_stride, void* stream);
 int tcx_unpatchify(const void* x, void* out, int32_t B, int32_t F, int32_t C, int32_t H, int32_t W,
                    int32_t p, int32_t out_dtype, void* stream);
 

@@ -296,6 +296,8 @@ def test_patchify_unpatchify_bit_exact(ops):
     ref = F.unfold(x.reshape(B * Fr, 33, H, W).float(), kernel_size=p, stride=p).transpose(1, 2).reshape(-1, 33 * p * p)
     got = ops.patchify(dev(a), dev(b), p)
     assert torch.equal(got.float().cpu(), ref)
+    padded = ops.patchify(dev(a), dev(b), p, k_pad=128).float().cpu()       # rows zero-filled to K = 256 for the GEMM
+    assert padded.shape == (ref.shape[0], 256) and torch.equal(padded[:, :132], ref) and float(padded[:, 132:].abs().max()) == 0
     tok = bf(torch.randn(B, Fr * (H // p) * (W // p), 16 * p * p, generator=g))
     r = tok.reshape(B, Fr, H // p, W // p, 16, p, p).permute(0, 1, 4, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
     got = ops.unpatchify(dev(tok), B, Fr, 16, H, W, p)

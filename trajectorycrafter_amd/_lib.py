@@ -29,7 +29,7 @@ SIGNATURES = {
     "tcx_bias_gelu_tanh": [_vp, _vp, _vp, _i64, _i32, _vp],
     "tcx_scale_bf16": [_vp, _vp, _i64, _f32, _vp],
     "tcx_silu_bf16": [_vp, _vp, _i64, _vp],
-    "tcx_patchify": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "tcx_patchify": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "tcx_unpatchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "tcx_cfg_ddim_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _vp],
     "tcx_conv3d_cl": [_vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 16 + [_vp, _vp],

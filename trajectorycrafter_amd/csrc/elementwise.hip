@@ -85,14 +85,16 @@ __global__ __launch_bounds__(256) void unary_kernel(const uint16_t* x, uint16_t*
     }
 }
 
-// out[(b,f,gy,gx), (c,ky,kx)] = in[b,f,c, gy*p+ky, gx*p+kx], c over the concat of a (Ca ch) and b (Cb ch)
+// out[(b,f,gy,gx), (c,ky,kx)] = in[b,f,c, gy*p+ky, gx*p+kx], c over the concat of a (Ca ch) and b (Cb ch); rows are
+// ks >= K elements long, zero-filled past K (the GEMM wants K % 128 == 0)
 __global__ __launch_bounds__(256) void patchify_kernel(const uint16_t* a, const uint16_t* bsrc, uint16_t* out,
-                                                       int32_t BF, int32_t Ca, int32_t Cb, int32_t H, int32_t W, int32_t p) {
+                                                       int32_t BF, int32_t Ca, int32_t Cb, int32_t H, int32_t W, int32_t p, int32_t ks) {
     const int gh = H / p, gw = W / p, Ct = Ca + Cb, K = Ct * p * p;
-    const int64_t n = (int64_t)BF * gh * gw * K;
+    const int64_t n = (int64_t)BF * gh * gw * ks;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int kk = (int)(i % K);
-        const int64_t m = i / K;
+        const int kk = (int)(i % ks);
+        const int64_t m = i / ks;
+        if (kk >= K) { out[i] = 0; continue; }
         const int gx = (int)(m % gw), gy = (int)((m / gw) % gh);
         const int64_t bf = m / ((int64_t)gw * gh);
         const int kx = kk % p, ky = (kk / p) % p, c = kk / (p * p);
@@ -263,14 +265,16 @@ extern "C" int tcx_silu_bf16(const void* x, void* y, int64_t n, void* stream) {
 }
 
 extern "C" int tcx_patchify(const void* a, const void* b, void* out, int32_t B, int32_t F, int32_t Ca, int32_t Cb,
-                            int32_t H, int32_t W, int32_t p, void* stream) {
+                            int32_t H, int32_t W, int32_t p, int32_t k_stride, void* stream) {
     TCX_CHECK(a && out, TCX_E_NULL, "tcx_patchify: null pointer");
     TCX_CHECK((b != nullptr) == (Cb > 0), TCX_E_NULL, "tcx_patchify: b must be given iff Cb > 0");
     TCX_CHECK(B > 0 && F > 0 && Ca > 0 && Cb >= 0 && p > 0 && H % p == 0 && W % p == 0, TCX_E_SHAPE,
               "tcx_patchify: H=%d, W=%d must be divisible by patch %d", H, W, p);
-    const int64_t n = (int64_t)B * F * (H / p) * (W / p) * (Ca + Cb) * p * p;
+    if (k_stride == 0) k_stride = (Ca + Cb) * p * p;
+    TCX_CHECK(k_stride >= (Ca + Cb) * p * p, TCX_E_SHAPE, "tcx_patchify: k_stride=%d is shorter than a row (%d)", k_stride, (Ca + Cb) * p * p);
+    const int64_t n = (int64_t)B * F * (H / p) * (W / p) * k_stride;
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a,
-                       (const uint16_t*)b, (uint16_t*)out, B * F, Ca, Cb, H, W, p);
+                       (const uint16_t*)b, (uint16_t*)out, B * F, Ca, Cb, H, W, p, k_stride);
     TCX_LAUNCH_RET();
 }
 

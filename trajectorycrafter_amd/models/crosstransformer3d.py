@@ -47,8 +47,8 @@ def _linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, 
     """y = epilogue(x @ w.T + b), bf16 in / fp32 accumulate / bf16 out, on the hand-written MFMA kernel
     (`tcx_gemm_bf16`) for every shape it takes (N % 8 == 0, K % 128 == 0: all Linears of the blocks, embeddings and
     modulations of the 5B model).  GEMM_GATED_RESIDUAL updates `res` in place and returns it.
-    Other shapes (the K = 132 patch embedding; narrow test configurations) are a plain library GEMM followed by the
-    stand-alone HIP epilogue kernels."""
+    Other shapes (K % 128 != 0: narrow test configurations only — the patch embeddings are zero-padded to K = 256 / 128)
+    are a plain library GEMM followed by the stand-alone HIP epilogue kernels."""
     if ops.gemm_supported(w.shape[0], w.shape[1]):
         if epilogue == ops.GEMM_GATED_RESIDUAL:
             return ops.gemm_bf16(x, w, b, epilogue=epilogue, res=res, gate_v=gate_v, gate_t=gate_t, text_len=text_len, out=res)
@@ -59,6 +59,18 @@ def _linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, 
     if epilogue == ops.GEMM_GATED_RESIDUAL:
         return ops.gated_residual_(res, y.view(res.shape), gate_v, gate_t, text_len)
     return y
+
+
+def _conv_as_gemm_weight(conv: nn.Conv2d, cache: dict) -> torch.Tensor:
+    """Conv2d(k = p, stride = p) weight as the [N, K] matrix of the im2col GEMM, K zero-padded to a multiple of 128 (what
+    `tcx_gemm_bf16` takes; `ops.patchify(.., k_pad=128)` pads the activations the same way).  Cached per weight version."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version)
+    if cache.get("key") != key:
+        flat = w.detach().flatten(1)
+        K = flat.shape[1]
+        cache["key"], cache["w"] = key, F.pad(flat, (0, (-K) % 128)).contiguous()
+    return cache["w"]
 
 
 def _require_hip(t: torch.Tensor, what: str) -> None:
@@ -80,8 +92,8 @@ class CogVideoXPatchEmbed(nn.Module):
     def forward(self, text_embeds: torch.Tensor, image_embeds: torch.Tensor, extra: Optional[torch.Tensor] = None):
         """-> joint [B, text_len + F*h'*w', D] (text first).  `extra` is channel-concatenated (inpaint latents)."""
         B, Fr = image_embeds.shape[:2]
-        cols = ops.patchify(image_embeds, extra, self.patch_size)
-        vid = _linear(cols, self.proj.weight.flatten(1), self.proj.bias).view(B, -1, self.proj.out_channels)
+        cols = ops.patchify(image_embeds, extra, self.patch_size, k_pad=128)
+        vid = _linear(cols, _conv_as_gemm_weight(self.proj, self.__dict__.setdefault("_gemm_w", {})), self.proj.bias).view(B, -1, self.proj.out_channels)
         text = _linear(text_embeds, self.text_proj.weight, self.text_proj.bias)
         return torch.cat([text, vid], dim=1)
 
@@ -97,8 +109,8 @@ class RefPatchEmbed(nn.Module):
     def forward(self, image_embeds: torch.Tensor):
         B = image_embeds.shape[0]
         image_embeds = image_embeds.to(self.proj.weight.device)          # reference :123-125
-        cols = ops.patchify(image_embeds, None, self.patch_size)
-        return _linear(cols, self.proj.weight.flatten(1), self.proj.bias).view(B, -1, self.proj.out_channels)
+        cols = ops.patchify(image_embeds, None, self.patch_size, k_pad=128)
+        return _linear(cols, _conv_as_gemm_weight(self.proj, self.__dict__.setdefault("_gemm_w", {})), self.proj.bias).view(B, -1, self.proj.out_channels)
 
 
 class CogVideoXLayerNormZero(nn.Module):

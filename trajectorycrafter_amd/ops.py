@@ -188,8 +188,9 @@ def silu(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def patchify(a: torch.Tensor, b: Optional[torch.Tensor], p: int) -> torch.Tensor:
-    """[B,F,Ca,H,W] (+ [B,F,Cb,H,W]) -> [B*F*(H/p)*(W/p), (Ca+Cb)*p*p]."""
+def patchify(a: torch.Tensor, b: Optional[torch.Tensor], p: int, k_pad: int = 1) -> torch.Tensor:
+    """[B,F,Ca,H,W] (+ [B,F,Cb,H,W]) -> [B*F*(H/p)*(W/p), K], K = (Ca+Cb)*p*p rounded up to a multiple of k_pad
+    (zero-filled: `gemm_bf16` wants K % 128 == 0)."""
     _need(a, "a")
     a = a.contiguous()
     B, F, Ca, H, W = a.shape
@@ -200,8 +201,10 @@ def patchify(a: torch.Tensor, b: Optional[torch.Tensor], p: int) -> torch.Tensor
         if b.shape[:2] != (B, F) or b.shape[3:] != (H, W):
             raise TcxError(f"patchify: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
         Cb = b.shape[2]
-    out = torch.empty((B * F * (H // p) * (W // p), (Ca + Cb) * p * p), device=a.device, dtype=BF16)
-    check(_lib.load().tcx_patchify(_p(a), _p(b), _p(out), B, F, Ca, Cb, H, W, p, _stream()), "tcx_patchify")
+    K = (Ca + Cb) * p * p
+    ks = (K + k_pad - 1) // k_pad * k_pad
+    out = torch.empty((B * F * (H // p) * (W // p), ks), device=a.device, dtype=BF16)
+    check(_lib.load().tcx_patchify(_p(a), _p(b), _p(out), B, F, Ca, Cb, H, W, p, ks, _stream()), "tcx_patchify")
     return out
 
 
