@@ -19,7 +19,8 @@
 //  * The two wave rows run one barrier apart (wr = 1 takes one extra s_barrier before the loop, wr = 0 one after it):
 //    while one wave of a SIMD issues its 16 MFMAs the other reads fragments and issues the LDS-DMA.
 //  * Ordering, per phase and wave:  ds_reads ; stage (2 glds) ; [vmcnt(6) in phases 3 and 7] ; lgkmcnt(0) ; s_barrier ;
-//    16 MFMA ; s_barrier.  With L_p / M_p the load / MFMA segments and k_j the j-th barrier, wave row 0 runs L_p in
+//    16 MFMA ; s_barrier.  (Measured with tools/exp_gemm.sh: without the stagger -14 %; lgkmcnt(0) moved behind the
+//    barrier — which would break the WAR argument below — gains nothing; s_setprio around the MFMAs -0.5..-1 %.)  With L_p / M_p the load / MFMA segments and k_j the j-th barrier, wave row 0 runs L_p in
 //    (k_2p, k_2p+1) and wave row 1 in (k_2p+1, k_2p+2):
 //      WAR: reads of phase p have returned (lgkmcnt(0)) before k_2p+2 at the latest; the earliest stage of phase q is
 //           issued after k_2q  ->  re-staging in phase q >= p + 1 is safe.
@@ -42,7 +43,10 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF = 128 * BK * 2;   // 16 KiB: 128 rows x 64 bf16
 constexpr int BUF = 4 * HALF;        // X0 X1 W0 W1
 constexpr int LDS_BYTES = 2 * BUF;
-constexpr int GM = 4;                // M-tiles per band of the tile order
+#ifndef TCX_GEMM_GM
+#define TCX_GEMM_GM 4
+#endif
+constexpr int GM = TCX_GEMM_GM;      // M-tiles per band of the tile order
 
 struct GemmParams {
     const uint16_t *x, *w, *bias;
@@ -144,7 +148,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
     };
     auto mfma_quadrant = [&](auto qmsel, auto qnsel) __attribute__((always_inline)) {
         constexpr int QM = decltype(qmsel)::value, QN = decltype(qnsel)::value;
+#ifdef TCX_GEMM_EXP_PRIO               // s_setprio(1) around the MFMA cluster: measured -0.5..-1 % here, off
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -153,7 +159,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
                 for (int u = 0; u < 2; ++u)
                     acc[QM * 4 + tt][QN * 2 + u] =
                         __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][ks], xf[tt][ks], acc[QM * 4 + tt][QN * 2 + u], 0, 0, 0);
+#ifdef TCX_GEMM_EXP_PRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
     };
     // one phase: P = 0..7 (P >> 2 = buffer being computed), kt2 = even K-tile of this iteration
     auto phase = [&](auto psel, int kt2) __attribute__((always_inline)) {
@@ -173,7 +181,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
         if constexpr (P == 7) stage(H1{}, 1, kt2 + 3);
         TCX_SB();
         if constexpr (Q == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#ifndef TCX_GEMM_EXP_LGKM_AFTER      // timing experiment only: reads may still be in flight when the partner re-stages
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         TCX_SB();
@@ -198,7 +208,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifndef TCX_GEMM_EXP_NOSTAGGER
     if (wr == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs one barrier behind
+#endif
     TCX_SB();
 
     for (int kt2 = 0; kt2 < KT; kt2 += 2) {
@@ -211,7 +223,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
         phase(std::integral_constant<int, 6>{}, kt2);
         phase(std::integral_constant<int, 7>{}, kt2);
     }
+#ifndef TCX_GEMM_EXP_NOSTAGGER
     if (wr == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the trailing (unused) LDS-DMA must land before the LDS is released
 
     // ---- epilogue: lane holds C[m = .. + fi][n = .. + 4 fg + 0..3] of each 16x16 tile ----
