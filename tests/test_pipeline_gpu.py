@@ -116,3 +116,40 @@ def test_pipeline_from_pixels_runs_end_to_end(setup):
     assert torch.equal(a, b)                       # same device-RNG seed -> same reference-latent sample -> same frames
     # (no comparison with the fixture frames here: the reference-frame posterior is *sampled* from the device RNG,
     #  reference :886; the deterministic parts are pinned in test_conditioning_from_pixels_matches_oracle)
+
+
+def test_driver_render_then_generate(setup):
+    """Thin driver (reference demo.py:75-148 from frames + depths + poses on): the rendered conditioning equals the
+    oracle's per-frame point-cloud render + the same resizes, and the whole chain render -> encode -> denoise -> decode
+    runs on the GPU and is deterministic."""
+    import torch.nn.functional as F
+    from oracle import warp as owarp
+    from trajectorycrafter_amd import driver
+    from trajectorycrafter_amd.models.utils import Warper
+    s, tp = setup, setup["tp"]
+    g = torch.Generator().manual_seed(21)
+    T, H, W = 9, 48, 80
+    frames = torch.rand(T, 3, H, W, generator=g) * 2 - 1
+    depths = 2.0 + torch.rand(T, 1, H, W, generator=g)
+    K = torch.tensor([[50.0, 0, W / 2], [0, 50.0, H / 2], [0, 0, 1]])[None].repeat(T, 1, 1)
+    pose_s = torch.eye(4)[None].repeat(T, 1, 1)
+    pose_t = pose_s.clone()
+    pose_t[:, 0, 3] = torch.linspace(0, 0.4, T)                      # the camera slides sideways over the clip
+    wp = Warper(device="cuda:0")
+    video, mask_video, reference = driver.render_conditioning(wp, frames, depths, pose_s, pose_t, K, (32, 48), ref_frames=5)
+    assert video.shape == (1, 3, T, 32, 48) and mask_video.shape == (1, 1, T, 32, 48) and reference.shape == (1, 3, 5, 32, 48)
+    parts = [owarp.forward_warp(frames[i:i + 1], None, depths[i:i + 1], pose_s[i:i + 1], pose_t[i:i + 1], K[i:i + 1]) for i in range(T)]
+    ow, om = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+    want_video = F.interpolate((ow + 1) / 2, size=(32, 48), mode="bilinear", align_corners=False).permute(1, 0, 2, 3)[None]
+    want_mask = (1 - F.interpolate(om, size=(32, 48), mode="nearest").permute(1, 0, 2, 3)[None]) * 255
+    assert float((mask_video.cpu() != want_mask).float().mean()) < 2e-3
+    assert float((video.cpu() - want_video).abs().max()) < 2e-2 and float((video.cpu() - want_video).abs().mean()) < 1e-4
+    assert set(mask_video.unique().tolist()) <= {0.0, 255.0} and 0 < float(mask_video.mean()) < 255
+    kw = dict(sample_size=(32, 48), prompt_embeds=tp["prompt_embeds"].to(BF), negative_prompt_embeds=tp["negative_prompt_embeds"].to(BF),
+              num_inference_steps=2, seed=7, latents=tp["latents0"].to(BF))
+    torch.manual_seed(3)
+    a = driver.render_and_generate(s["pipe"], wp, frames, depths, pose_s, pose_t, K, **kw)
+    torch.manual_seed(3)
+    b = driver.render_and_generate(s["pipe"], wp, frames, depths, pose_s, pose_t, K, **kw)
+    assert a.shape == (1, 3, T, 32, 48) and torch.isfinite(a).all() and float(a.min()) >= 0 and float(a.max()) <= 1
+    assert torch.equal(a, b)
