@@ -405,6 +405,81 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         }
     };
 
+    // Fine-grained variant of the tile body for the bound-centred D = 64 loop: every MFMA is followed by exactly
+    // {2 exp, 2 add, 1 cvt} (36.5 issue cycles per 32-cycle MFMA, MI355X_MICROARCH.md issue costs) instead of
+    // {2 MFMA, 8 exp + 8 add + 4 cvt, 2 MFMA}: with the bunched order the two barrier-locked waves of a SIMD want the
+    // matrix pipe at the same time and the vector issue at the same time, and their times ADD; with the alternating
+    // order they slip one MFMA apart and mesh.  The PV product of a 16-key step is delayed by one step (pprev / vprev:
+    // its P fragment and V fragments stay in registers) so that it can alternate with the next step's exponentials;
+    // the last one is flushed after the loop.
+#ifdef TCX_EXP_NOFINE
+    constexpr bool FINE = false;
+#else
+    constexpr bool FINE = BOUND && FAST && D == 64 && !kSumMfma;
+#endif
+    bf16x8 pprev, vprev[DT];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pprev[j] = (__bf16)0.0f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vprev[dt] = pprev;
+    auto tile_body_fine = [&](auto has_next, const char* kb, const char* vb, f32x16 (&cur)[2], f32x16 (&nxt)[2]) __attribute__((always_inline)) {
+        constexpr bool NEXT = decltype(has_next)::value;
+        bf16x8 kfa[2], kfb[2];
+        auto read_k = [&](int st, bf16x8 (&kf)[2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(kb + koff[st] + t * K_T_STRIDE);
+        };
+        auto read_v = [&](int st, int dt, bf16x8& vf) __attribute__((always_inline)) {
+            const int rowb = (32 * (st >> 1) + 16 * (st & 1)) * (D * 2);
+            auto p0 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + rowb);
+            auto p1 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + rowb + 8 * (D * 2));
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p1);
+            vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        if constexpr (NEXT) {
+            read_k(0, kfa);
+            qk_init(nxt);
+        }
+        auto step = [&](int st, bf16x8 (&kf)[2], bf16x8 (&kfn)[2]) __attribute__((always_inline)) {
+            const int t = st >> 1, s2 = st & 1;
+            bf16x8 pf, vcur[DT];
+            auto soft2 = [&](int j0) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = j0; j < j0 + 2; ++j) {
+                    const float e = __builtin_amdgcn_exp2f(cur[t][8 * s2 + j]);
+                    ls[j & 3] += e;
+                    pf[j] = (__bf16)e;
+                }
+            };
+            if constexpr (NEXT) {
+                if (st < 3) read_k(st + 1, kfn);
+            }
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vprev[0], pprev, o[0], 0, 0, 0);
+            soft2(0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_v(st, 0, vcur[0]);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vprev[1], pprev, o[1], 0, 0, 0);
+            soft2(2);
+            __builtin_amdgcn_sched_barrier(0);
+            read_v(st, 1, vcur[1]);
+            if constexpr (NEXT) nxt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[st], nxt[0], 0, 0, 0);
+            soft2(4);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NEXT) nxt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[st], nxt[1], 0, 0, 0);
+            soft2(6);
+            asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]));
+            __builtin_amdgcn_sched_barrier(0);
+            pprev = pf;
+            vprev[0] = vcur[0];
+            vprev[1] = vcur[1];
+        };
+        step(0, kfa, kfb);
+        step(1, kfb, kfa);
+        step(2, kfa, kfb);
+        step(3, kfb, kfa);
+    };
+
     // Software pipeline over 64-key tiles; staging and synchronisation in rounds of TPB tiles ("super-steps").
     // Tile t lives in ring slot t % R of its operand.  At the start of the super-step of tiles t0 .. t0+TPB-1 the
     // ring holds K[t0+1 .. t0+TPB] and V[t0 .. t0+TPB-1]; the super-step issues the global loads of
@@ -416,7 +491,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     constexpr std::integral_constant<int, TPB - 1> J1{};
     f32x16 sa[2], sb[2];
     auto one_tile = [&](auto bnd, auto slot_k, auto slot_v, int tile, f32x16 (&cur)[2], f32x16 (&nxt)[2]) __attribute__((always_inline)) {
-        tile_body(std::true_type{}, kbuf0 + decltype(slot_k)::value * TILEB, vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
+        if constexpr (FINE) tile_body_fine(std::true_type{}, kbuf0 + decltype(slot_k)::value * TILEB, vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
+        else tile_body(std::true_type{}, kbuf0 + decltype(slot_k)::value * TILEB, vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
         if (tile + 1 == ntiles - 1 && (p.Sk & 63)) mask_tail(nxt);
         if constexpr (!decltype(bnd)::value) row_max_and_rescale(nxt);   // bound-centred loop: the reference max never moves
         else __builtin_amdgcn_sched_barrier(0);                         // keep tiles apart (register pressure)
@@ -456,9 +532,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         if constexpr (TPB == 2) {
             if (rem == 1) {
                 one_tile(bnd, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
-                tile_body(std::false_type{}, kbuf0, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
+                if constexpr (FINE) tile_body_fine(std::false_type{}, kbuf0, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
+                else tile_body(std::false_type{}, kbuf0, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
             } else {
-                tile_body(std::false_type{}, kbuf0, vbuf0 + (PH % R) * TILEB, sa, sb);
+                if constexpr (FINE) tile_body_fine(std::false_type{}, kbuf0, vbuf0 + (PH % R) * TILEB, sa, sb);
+                else tile_body(std::false_type{}, kbuf0, vbuf0 + (PH % R) * TILEB, sa, sb);
             }
         } else {
             (void)rem;
@@ -503,6 +581,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         }
     };
     run(std::integral_constant<bool, BOUND>{});
+    if constexpr (FINE) {                 // the delayed PV product of the very last 16-key step
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vprev[dt], pprev, o[dt], 0, 0, 0);
+    }
     if constexpr (!(FAST && kSumMfma)) l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
 
     // ---- epilogue: combine the two half-wave partial sums, normalise, store O[q][d] ----
