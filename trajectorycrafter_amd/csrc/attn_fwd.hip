@@ -444,13 +444,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         auto step = [&](int st, bf16x8 (&kf)[2], bf16x8 (&kfn)[2]) __attribute__((always_inline)) {
             const int t = st >> 1, s2 = st & 1;
             bf16x8 pf, vcur[DT];
+            u32x4 pw;
             auto soft2 = [&](int j0) __attribute__((always_inline)) {
-#pragma unroll
-                for (int j = j0; j < j0 + 2; ++j) {
-                    const float e = __builtin_amdgcn_exp2f(cur[t][8 * s2 + j]);
-                    ls[j & 3] += e;
-                    pf[j] = (__bf16)e;
-                }
+                const float e0 = __builtin_amdgcn_exp2f(cur[t][8 * s2 + j0]);
+                const float e1 = __builtin_amdgcn_exp2f(cur[t][8 * s2 + j0 + 1]);
+                ls[j0 & 3] += e0;
+                ls[(j0 + 1) & 3] += e1;
+                uint32_t w = pack_bf16(e0, e1);
+                asm volatile("" : "+v"(w));              // convert here, inside this MFMA gap (the compiler sinks all four to the step's end)
+                pw[j0 >> 1] = w;
             };
             if constexpr (NEXT) {
                 if (st < 3) read_k(st + 1, kfn);
@@ -470,6 +472,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             soft2(6);
             asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]));
             __builtin_amdgcn_sched_barrier(0);
+            pf = __builtin_bit_cast(bf16x8, pw);
             pprev = pf;
             vprev[0] = vcur[0];
             vprev[1] = vcur[1];
