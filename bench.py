@@ -210,13 +210,16 @@ def main():
         if os.path.exists(pmc) and (args.frames, args.height, args.width) == (49, 480, 720):   # committed rocprofv3 --pmc result
             with open(pmc) as f:
                 traffic = json.load(f).get("traffic_bytes_per_launch")
+        benchmark_config = (args.denoise_steps, args.height, args.width, args.frames, args.layers, args.no_decode) == (50, 480, 720, 49, 42, False)
         rec = {
             "metric": "denoised video-latents/sec (49f, 480x720)", "value": world * args.steps / elapsed,
             "unit": "video-latents/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[2]: full 50-step DDIM (CFG 6, B=2 per step) + VAE decode, 49f 480x720, "
-                                   "random-init " + str(args.layers) + "-layer CrossTransformer3D (42 layers = the 6.1 B-param 5B model); one independent trajectory per GPU",
+            "config": {"workload": ("configs[2]: full 50-step DDIM (CFG 6, B=2 per step) + VAE decode, 49f 480x720, random-init 42-layer "
+                                    "CrossTransformer3D (the 6.1 B-param 5B model); one independent trajectory per GPU") if benchmark_config else
+                                   (f"DEBUG (not the benchmark config): {args.denoise_steps}-step DDIM, {args.frames}f {args.height}x{args.width}, "
+                                    f"{args.layers} layers, decode={not args.no_decode}"),
                        "frames": args.frames, "height": args.height, "width": args.width, "denoise_steps": args.denoise_steps,
                        "layers": args.layers, "vae_decode": not args.no_decode, "global_batch_clips": world,
                        "parallelism": f"dp{world}", "last_clip_denoise_s": tm["denoise_s"], "last_clip_decode_s": tm["decode_s"],
