@@ -422,13 +422,22 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     for (int j = 0; j < 8; ++j) pprev[j] = (__bf16)0.0f;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) vprev[dt] = pprev;
-    auto tile_body_fine = [&](auto has_next, const char* kb, const char* vb, f32x16 (&cur)[2], f32x16 (&nxt)[2]) __attribute__((always_inline)) {
-        constexpr bool NEXT = decltype(has_next)::value;
-        bf16x8 kfa[2], kfb[2];
-        auto read_k = [&](int st, bf16x8 (&kf)[2]) __attribute__((always_inline)) {
+    // K fragments of the NEXT tile's first step are fetched during this tile's last step when that K tile is already
+    // resident (first tile of a super-step): otherwise every tile starts by waiting one LDS round trip for them
+    bf16x8 kfa[2], kfb[2];
+    auto tile_body_fine = [&](auto has_next, auto prefetched, const char* kb, const char* kb_after, const char* vb, f32x16 (&cur)[2],
+                              f32x16 (&nxt)[2]) __attribute__((always_inline)) {
+#ifdef TCX_EXP_NOKPRE
+        constexpr bool NEXT = decltype(has_next)::value, PRE = false;
+        kb_after = nullptr;
+#else
+        constexpr bool NEXT = decltype(has_next)::value, PRE = decltype(prefetched)::value;
+#endif
+        auto read_k_from = [&](const char* base, int st, bf16x8 (&kf)[2]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(kb + koff[st] + t * K_T_STRIDE);
+            for (int t = 0; t < 2; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(base + koff[st] + t * K_T_STRIDE);
         };
+        auto read_k = [&](int st, bf16x8 (&kf)[2]) __attribute__((always_inline)) { read_k_from(kb, st, kf); };
         auto read_v = [&](int st, int dt, bf16x8& vf) __attribute__((always_inline)) {
             const int rowb = (32 * (st >> 1) + 16 * (st & 1)) * (D * 2);
             auto p0 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + rowb);
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         };
         if constexpr (NEXT) {
-            read_k(0, kfa);
+            if constexpr (!PRE) read_k(0, kfa);
             qk_init(nxt);
         }
         auto step = [&](int st, bf16x8 (&kf)[2], bf16x8 (&kfn)[2]) __attribute__((always_inline)) {
@@ -456,6 +465,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             };
             if constexpr (NEXT) {
                 if (st < 3) read_k(st + 1, kfn);
+                else if (kb_after) read_k_from(kb_after, 0, kfn);      // step 3: kfn is kfa, what the next tile's step 0 uses
             }
             o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vprev[0], pprev, o[0], 0, 0, 0);
             soft2(0);
@@ -493,8 +503,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     constexpr std::integral_constant<int, 0> J0{};
     constexpr std::integral_constant<int, TPB - 1> J1{};
     f32x16 sa[2], sb[2];
-    auto one_tile = [&](auto bnd, auto slot_k, auto slot_v, int tile, f32x16 (&cur)[2], f32x16 (&nxt)[2]) __attribute__((always_inline)) {
-        if constexpr (FINE) tile_body_fine(std::true_type{}, kbuf0 + decltype(slot_k)::value * TILEB, vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
+    auto one_tile = [&](auto bnd, auto slot_k, auto slot_v, int tile, f32x16 (&cur)[2], f32x16 (&nxt)[2], auto prefetched,
+                        const char* kb_after) __attribute__((always_inline)) {
+        if constexpr (FINE) tile_body_fine(std::true_type{}, prefetched, kbuf0 + decltype(slot_k)::value * TILEB, kb_after,
+                                           vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
         else tile_body(std::true_type{}, kbuf0 + decltype(slot_k)::value * TILEB, vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
         if (tile + 1 == ntiles - 1 && (p.Sk & 63)) mask_tail(nxt);
         if constexpr (!decltype(bnd)::value) row_max_and_rescale(nxt);   // bound-centred loop: the reference max never moves
@@ -509,11 +521,14 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             load_v(J1, t0 + TPB + 1);
         }
         if constexpr (TPB == 2) {
-            one_tile(bnd, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
-            one_tile(bnd, std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa);
+            // the second tile's K slot ((PH + 2) % R) is resident for the whole super-step: its first fragments are prefetched
+            one_tile(bnd, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb, std::false_type{},
+                     kbuf0 + ((PH + 2) % R) * TILEB);
+            one_tile(bnd, std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa, std::true_type{},
+                     nullptr);
         } else {
-            if constexpr (PH == 0) one_tile(bnd, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t0, sa, sb);
-            else one_tile(bnd, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t0, sb, sa);
+            if constexpr (PH == 0) one_tile(bnd, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t0, sa, sb, std::false_type{}, nullptr);
+            else one_tile(bnd, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t0, sb, sa, std::false_type{}, nullptr);
         }
 #ifndef TCX_EXP_NOWRITE
         write_k(J0, (PH + TPB + 1) % R);
@@ -534,11 +549,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         const int rem = (ntiles - 1) - t0;                   // 0 .. TPB-1
         if constexpr (TPB == 2) {
             if (rem == 1) {
-                one_tile(bnd, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
-                if constexpr (FINE) tile_body_fine(std::false_type{}, kbuf0, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
+                one_tile(bnd, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb, std::false_type{}, nullptr);
+                if constexpr (FINE) tile_body_fine(std::false_type{}, std::false_type{}, kbuf0, nullptr, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
                 else tile_body(std::false_type{}, kbuf0, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
             } else {
-                if constexpr (FINE) tile_body_fine(std::false_type{}, kbuf0, vbuf0 + (PH % R) * TILEB, sa, sb);
+                if constexpr (FINE) tile_body_fine(std::false_type{}, std::false_type{}, kbuf0, nullptr, vbuf0 + (PH % R) * TILEB, sa, sb);
                 else tile_body(std::false_type{}, kbuf0, vbuf0 + (PH % R) * TILEB, sa, sb);
             }
         } else {
