@@ -84,10 +84,9 @@ def main():
             w = rn(N, K) * 0.02
             xx = x if K == Dm else rn(B * S, K)
             ms = timeit(lambda: torch.nn.functional.linear(xx, w), iters)
-            report(f"hipBLASLt {name} M={B * S}", ms, flops=2.0 * B * S * N * K)
-            if os.environ.get("TCX_BENCH_HIPGEMM", "1") == "1":
-                ms = timeit(lambda: ops.linear_hip(xx, w), max(3, iters // 2))
-                report(f"  hand igemm {name}", ms, flops=2.0 * B * S * N * K)
+            report(f"library GEMM {name} M={B * S}", ms, flops=2.0 * B * S * N * K)
+            ms = timeit(lambda: ops.gemm_bf16(xx, w), iters)
+            report(f"  tcx_gemm_bf16 {name}", ms, flops=2.0 * B * S * N * K)
     if "rows" in which:
         x = rn(B, S, Dm)
         gam, bet = rn(Dm), rn(Dm)

@@ -1,8 +1,8 @@
 """Thin torch-tensor front end over the C ABI (libtcx_hip.so).
 
-torch is used for device memory, streams and (for now) the plain library GEMMs (hipBLASLt through
-`F.linear`); every other hot-path op is a hand-written HIP kernel reached through ctypes.  Nothing
-here falls back to torch arithmetic: a missing library or a failing launch raises `TcxError`.
+torch is used for device memory and streams; every hot-path op, the GEMMs included (`gemm_bf16`), is a
+hand-written HIP kernel reached through ctypes.  Nothing here falls back to torch arithmetic: a missing
+library or a failing launch raises `TcxError`.
 """
 from __future__ import annotations
 
@@ -277,16 +277,6 @@ def avgpool_t(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty((N, To, H, W, Cc), device=x.device, dtype=BF16)
     check(_lib.load().tcx_avgpool_t(_p(x), _p(y), N, T, H * W, Cc, _stream()), "tcx_avgpool_t")
     return y
-
-
-def linear_hip(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
-               res: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = x @ w.T + bias (+ res) through the hand-written implicit-GEMM kernel (1x1x1 convolution)."""
-    Cout, Cin = w.shape
-    xs = x.reshape(1, 1, 1, -1, Cin)
-    r = None if res is None else res.reshape(1, 1, 1, -1, Cout)
-    y = conv3d_cl(xs, w.reshape(Cout, 1, 1, 1, Cin), bias, res=r)
-    return y.reshape(*x.shape[:-1], Cout)
 
 
 GEMM_BIAS, GEMM_BIAS_GELU, GEMM_GATED_RESIDUAL = 0, 1, 2
