@@ -133,3 +133,34 @@ def test_pipeline_rejects_cpu_models_and_checks_inputs():
         pipe(prompt="a", prompt_embeds=pe, height=32, width=48, num_frames=9)
     with pytest.raises(ValueError, match="no text encoder"):
         pipe.encode_prompt("hello", None, True, device="cpu")
+
+
+def test_gemm_row_geometry_decoding():
+    """Host logic of ops.gemm_bf16: how [.., N] views are mapped onto the C ABI's (rows_per_batch, ld, stride_b)."""
+    from trajectorycrafter_amd.ops import _gemm_rows, gemm_supported
+    from trajectorycrafter_amd._lib import TcxError
+    N = 16
+    assert _gemm_rows(torch.zeros(6, N), "t", N, 6) == (0, N, 0)                       # flat
+    assert _gemm_rows(torch.zeros(2, 3, N), "t", N, 6) == (0, N, 0)                    # contiguous [B, rows, N] collapses
+    assert _gemm_rows(torch.zeros(6, 3 * N)[:, N:2 * N], "t", N, 6) == (0, 3 * N, 0)   # column slice: ld > N
+    assert _gemm_rows(torch.zeros(2, 5, N)[:, 2:], "t", N, 6) == (3, N, 5 * N)         # row range of a joint buffer
+    assert _gemm_rows(torch.zeros(1, 5, N)[:, 2:], "t", N, 3) == (0, N, 0)             # batch of one: flat again
+    with pytest.raises(TcxError):
+        _gemm_rows(torch.zeros(6, N).t(), "t", 6, N)                                   # last dim not contiguous
+    with pytest.raises(TcxError):
+        _gemm_rows(torch.zeros(2, 2, 5, N)[:, :, 1:], "t", N, 16)                      # two strided levels
+    assert gemm_supported(3072, 3072) and gemm_supported(64, 3072) and gemm_supported(3072, 256)
+    assert not gemm_supported(3072, 132) and not gemm_supported(60, 128)
+
+
+def test_warper_and_driver_need_a_gpu():
+    """No CPU fallback in the product path: the CPU route is the oracle (oracle.warp)."""
+    from trajectorycrafter_amd.models.utils import Warper
+    from trajectorycrafter_amd._lib import TcxError
+    w = Warper(device="cpu")
+    f, d = torch.zeros(1, 3, 4, 4), torch.ones(1, 1, 4, 4)
+    eye, k = torch.eye(4)[None], torch.eye(3)[None]
+    with pytest.raises(TcxError):
+        w.forward_warp(f, None, d, eye, eye, k, None, False, twice=False)
+    with pytest.raises(NotImplementedError):
+        Warper(device="cuda:0").forward_warp(f, None, d, eye, eye, k, None, False, twice=True)
