@@ -229,52 +229,83 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the trailing (unused) LDS-DMA must land before the LDS is released
 
     // ---- epilogue: lane holds C[m = .. + fi][n = .. + 4 fg + 0..3] of each 16x16 tile ----
+    // Branch-free loads (out-of-range rows / columns read a clamped, valid address; only the stores are predicated) so
+    // that a row's residual and gate vectors are all in flight together instead of one L2 round trip each.
+    int ncol[4];
+    bool nok[4];
+    float bv[4][4];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const int64_t m = m0 + wr * 128 + a * 16 + fi;
-        if (m >= p.M) continue;
-        // rows_per_batch > 0: row m = (batch b, row rb); y / res / gates are addressed per batch (strided row ranges)
-        int64_t b = 0, rb = m;
-        if (p.rows_per_batch > 0) { b = m / p.rows_per_batch; rb = m - b * p.rows_per_batch; }
-        uint16_t* yrow = p.y + b * p.y_stride_b + rb * p.ldy;
-        const uint16_t* rrow = nullptr;
-        const uint16_t* gate = nullptr;
-        if constexpr (EPI == 2) {
-            rrow = p.res + b * p.res_stride_b + rb * p.ldres;
-            if (p.gate_v) gate = (rb < p.text_len ? p.gate_t : p.gate_v) + b * p.gate_stride_b;
-        }
-#pragma unroll
-        for (int bq = 0; bq < 4; ++bq) {
-            const int n = n0 + wc * 64 + bq * 16 + fg * 4;
-            if (n >= p.N) continue;                      // N % 4 == 0: a lane's four columns are in or out together
-            float v[4] = {acc[a][bq][0], acc[a][bq][1], acc[a][bq][2], acc[a][bq][3]};
-            if (p.bias) {
-                const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + n);
-                v[0] += bf16lo(bb[0]); v[1] += bf16hi(bb[0]); v[2] += bf16lo(bb[1]); v[3] += bf16hi(bb[1]);
-            }
-            if constexpr (EPI == 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_tanh_f(v[j]);
-            }
-            if constexpr (EPI == 2) {
-                const u32x2 rv = *reinterpret_cast<const u32x2*>(rrow + n);
-                float r[4] = {bf16lo(rv[0]), bf16hi(rv[0]), bf16lo(rv[1]), bf16hi(rv[1])};
-                if (gate) {
-                    const u32x2 gv = *reinterpret_cast<const u32x2*>(gate + n);
-                    const float gg[4] = {bf16lo(gv[0]), bf16hi(gv[0]), bf16lo(gv[1]), bf16hi(gv[1])};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = r[j] + gg[j] * v[j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = r[j] + v[j];
-                }
-            }
-            u32x2 o;
-            o[0] = pack_bf16(v[0], v[1]);
-            o[1] = pack_bf16(v[2], v[3]);
-            *reinterpret_cast<u32x2*>(yrow + n) = o;
-        }
+    for (int bq = 0; bq < 4; ++bq) {
+        const int n = n0 + wc * 64 + bq * 16 + fg * 4;
+        nok[bq] = n < p.N;                                   // N % 4 == 0: a lane's four columns are in or out together
+        ncol[bq] = nok[bq] ? n : p.N - 4;
+        u32x2 bb = {0u, 0u};
+        if (p.bias) bb = *reinterpret_cast<const u32x2*>(p.bias + ncol[bq]);
+        bv[bq][0] = bf16lo(bb[0]); bv[bq][1] = bf16hi(bb[0]); bv[bq][2] = bf16lo(bb[1]); bv[bq][3] = bf16hi(bb[1]);
     }
+    auto store_rows = [&](auto gated) __attribute__((always_inline)) {
+        constexpr bool GATED = decltype(gated)::value;
+        // row geometry of the lane's 8 rows; rows_per_batch > 0: row m = (batch b, row rb), y / res / gates are addressed
+        // per batch (strided row ranges)
+        bool mok[8];
+        uint32_t bb[8], rbb[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const uint32_t mr = (uint32_t)m0 + wr * 128 + a * 16 + fi;          // M < 2^31 (checked by the host)
+            mok[a] = mr < (uint32_t)p.M;
+            const uint32_t m = mok[a] ? mr : (uint32_t)p.M - 1;
+            bb[a] = 0;
+            rbb[a] = m;
+            if (p.rows_per_batch > 0) { bb[a] = m / (uint32_t)p.rows_per_batch; rbb[a] = m - bb[a] * (uint32_t)p.rows_per_batch; }
+        }
+        // all 32 residual vectors of the lane in flight at once (the fragment registers of the main loop are free now)
+        u32x2 rv[8][4];
+        if constexpr (EPI == 2) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const uint16_t* rrow = p.res + (int64_t)bb[a] * p.res_stride_b + (int64_t)rbb[a] * p.ldres;
+#pragma unroll
+                for (int bq = 0; bq < 4; ++bq) rv[a][bq] = *reinterpret_cast<const u32x2*>(rrow + ncol[bq]);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            uint16_t* yrow = p.y + (int64_t)bb[a] * p.y_stride_b + (int64_t)rbb[a] * p.ldy;
+            u32x2 gv[4];
+            if constexpr (EPI == 2 && GATED) {
+                const uint16_t* gate = (rbb[a] < (uint32_t)p.text_len ? p.gate_t : p.gate_v) + (int64_t)bb[a] * p.gate_stride_b;
+#pragma unroll
+                for (int bq = 0; bq < 4; ++bq) gv[bq] = *reinterpret_cast<const u32x2*>(gate + ncol[bq]);
+            }
+#pragma unroll
+            for (int bq = 0; bq < 4; ++bq) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[a][bq][j] + bv[bq][j];
+                if constexpr (EPI == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = gelu_tanh_f(v[j]);
+                }
+                if constexpr (EPI == 2) {
+                    const float r[4] = {bf16lo(rv[a][bq][0]), bf16hi(rv[a][bq][0]), bf16lo(rv[a][bq][1]), bf16hi(rv[a][bq][1])};
+                    if constexpr (GATED) {
+                        const float gg[4] = {bf16lo(gv[bq][0]), bf16hi(gv[bq][0]), bf16lo(gv[bq][1]), bf16hi(gv[bq][1])};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = r[j] + gg[j] * v[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = r[j] + v[j];
+                    }
+                }
+                u32x2 o;
+                o[0] = pack_bf16(v[0], v[1]);
+                o[1] = pack_bf16(v[2], v[3]);
+                if (mok[a] && nok[bq]) *reinterpret_cast<u32x2*>(yrow + ncol[bq]) = o;
+            }
+        }
+    };
+    if (EPI == 2 && p.gate_v) store_rows(std::true_type{});
+    else store_rows(std::false_type{});
 }
 
 template <int EPI>
@@ -296,6 +327,7 @@ extern "C" int tcx_gemm_bf16(const void* x, const void* w, const void* bias, voi
                              int64_t res_stride_b, const void* gate_v, const void* gate_t, int64_t gate_stride_b,
                              int32_t rows_per_batch, int32_t text_len, void* stream) {
     TCX_CHECK(x && w && y, TCX_E_NULL, "tcx_gemm_bf16: null x / w / y");
+    TCX_CHECK(M < (1ll << 31), TCX_E_SHAPE, "tcx_gemm_bf16: M=%lld exceeds 2^31 rows", (long long)M);
     TCX_CHECK(M > 0 && N > 0 && K > 0, TCX_E_SHAPE, "tcx_gemm_bf16: empty shape M=%lld N=%d K=%d", (long long)M, N, K);
     TCX_CHECK(N % 8 == 0 && K % (2 * BK) == 0, TCX_E_SHAPE, "tcx_gemm_bf16: needs N %% 8 == 0 and K %% 128 == 0 (N=%d K=%d)", N, K);
     TCX_CHECK(ldx >= K && ldy >= N && ldx % 8 == 0 && ldy % 4 == 0, TCX_E_SHAPE, "tcx_gemm_bf16: bad leading dimensions ldx=%lld ldy=%lld", (long long)ldx, (long long)ldy);
