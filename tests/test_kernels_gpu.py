@@ -369,7 +369,7 @@ def test_conv_pointwise_residual_and_linear(ops):
     assert_bf16_close(y, ref, atol=2e-3)
     xl = bf(torch.randn(3, 50, 200, generator=g))          # K = 200 (not a multiple of 32), ragged M
     wl = bf(torch.randn(72, 200, generator=g) / 14)
-    assert_bf16_close(ops.conv3d_cl(dev(xl).reshape(1, 1, 1, -1, xl.shape[-1]), dev(wl).reshape(wl.shape[0], 1, 1, 1, wl.shape[1]), None).reshape(-1, wl.shape[0]),
+    assert_bf16_close(ops.conv3d_cl(dev(xl).reshape(1, 1, 1, -1, xl.shape[-1]), dev(wl).reshape(wl.shape[0], 1, 1, 1, wl.shape[1]), None).reshape(3, 50, wl.shape[0]),
                       F.linear(xl.float(), wl.float()), atol=2e-3)       # 1x1x1 convolution == plain GEMM
 
 
