@@ -105,7 +105,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
     }
     auto stage = [&](auto hsel, int buf, int kt) __attribute__((always_inline)) {
         constexpr int H = decltype(hsel)::value;                        // 0 X0, 1 X1, 2 W0, 3 W1
-        kt = kt < KT ? kt : KT - 1;                                     // past the end: harmless re-load (keeps vmcnt counts)
+#ifndef TCX_GEMM_EXP_PEEL
+        kt = kt < KT ? kt : KT - 1;
+#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const uint16_t* src = (H < 2 ? px[H & 1][j] : pw[H & 1][j]) + (int64_t)kt * BK;
@@ -164,23 +166,29 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
 #endif
     };
     // one phase: P = 0..7 (P >> 2 = buffer being computed), kt2 = even K-tile of this iteration
-    auto phase = [&](auto psel, int kt2) __attribute__((always_inline)) {
+    // LAST = the tile's last iteration: only phase 0 still has something to stage (W half 0 of the odd K-tile); nothing
+    // is fetched past the end of K, and the single wait that remains is a vmcnt(0) with nothing else in flight.
+    auto phase = [&](auto psel, auto lastsel, int kt2) __attribute__((always_inline)) {
         constexpr int P = decltype(psel)::value, B = P >> 2, Q = P & 3;
+        constexpr bool LAST = decltype(lastsel)::value;
         if constexpr (Q == 0) { read_w(B, 0); TCX_SB(); read_x(B, 0); }
         if constexpr (Q == 1) read_w(B, 1);
         if constexpr (Q == 2) read_x(B, 1);
         if constexpr (Q == 3) read_w(B, 0);
         TCX_SB();
         if constexpr (P == 0) stage(H2{}, 1, kt2 + 1);
-        if constexpr (P == 1) stage(H0{}, 0, kt2 + 2);
-        if constexpr (P == 2) stage(H3{}, 0, kt2 + 2);
-        if constexpr (P == 3) stage(H1{}, 0, kt2 + 2);
-        if constexpr (P == 4) stage(H2{}, 0, kt2 + 2);
-        if constexpr (P == 5) stage(H0{}, 1, kt2 + 3);
-        if constexpr (P == 6) stage(H3{}, 1, kt2 + 3);
-        if constexpr (P == 7) stage(H1{}, 1, kt2 + 3);
+        if constexpr (!LAST) {
+            if constexpr (P == 1) stage(H0{}, 0, kt2 + 2);
+            if constexpr (P == 2) stage(H3{}, 0, kt2 + 2);
+            if constexpr (P == 3) stage(H1{}, 0, kt2 + 2);
+            if constexpr (P == 4) stage(H2{}, 0, kt2 + 2);
+            if constexpr (P == 5) stage(H0{}, 1, kt2 + 3);
+            if constexpr (P == 6) stage(H3{}, 1, kt2 + 3);
+            if constexpr (P == 7) stage(H1{}, 1, kt2 + 3);
+        }
         TCX_SB();
-        if constexpr (Q == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (Q == 3 && !LAST) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (P == 3 && LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef TCX_GEMM_EXP_LGKM_AFTER      // timing experiment only: reads may still be in flight when the partner re-stages
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -213,21 +221,28 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
 #endif
     TCX_SB();
 
-    for (int kt2 = 0; kt2 < KT; kt2 += 2) {
-        phase(std::integral_constant<int, 0>{}, kt2);
-        phase(std::integral_constant<int, 1>{}, kt2);
-        phase(std::integral_constant<int, 2>{}, kt2);
-        phase(std::integral_constant<int, 3>{}, kt2);
-        phase(std::integral_constant<int, 4>{}, kt2);
-        phase(std::integral_constant<int, 5>{}, kt2);
-        phase(std::integral_constant<int, 6>{}, kt2);
-        phase(std::integral_constant<int, 7>{}, kt2);
-    }
+    auto iteration = [&](auto lastsel, int kt2) __attribute__((always_inline)) {
+        phase(std::integral_constant<int, 0>{}, lastsel, kt2);
+        phase(std::integral_constant<int, 1>{}, lastsel, kt2);
+        phase(std::integral_constant<int, 2>{}, lastsel, kt2);
+        phase(std::integral_constant<int, 3>{}, lastsel, kt2);
+        phase(std::integral_constant<int, 4>{}, lastsel, kt2);
+        phase(std::integral_constant<int, 5>{}, lastsel, kt2);
+        phase(std::integral_constant<int, 6>{}, lastsel, kt2);
+        phase(std::integral_constant<int, 7>{}, lastsel, kt2);
+    };
+#ifdef TCX_GEMM_EXP_PEEL               // peeled last iteration (no loads past the end of K): measured 2-4 % SLOWER, off
+    for (int kt2 = 0; kt2 < KT - 2; kt2 += 2) iteration(std::false_type{}, kt2);
+    iteration(std::true_type{}, KT - 2);
+#else
+    // every iteration stages; past the end of K the last one re-loads the last K-tile into buffers nobody reads again
+    // (keeps the vmcnt counts, 7 half-tiles of extra L2 traffic per tile) and the loads are drained here
+    for (int kt2 = 0; kt2 < KT; kt2 += 2) iteration(std::false_type{}, kt2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing LDS-DMA must land before the LDS is released
+#endif
 #ifndef TCX_GEMM_EXP_NOSTAGGER
     if (wr == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count
 #endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the trailing (unused) LDS-DMA must land before the LDS is released
-
     // ---- epilogue: lane holds C[m = .. + fi][n = .. + 4 fg + 0..3] of each 16x16 tile ----
     // Branch-free loads (out-of-range rows / columns read a clamped, valid address; only the stores are predicated) so
     // that a row's residual and gate vectors are all in flight together instead of one L2 round trip each.
