@@ -129,4 +129,10 @@ def test_gemm_full_size_repeatable_and_linear(ops):
         d = (first.float() - ref.float()).abs()
         ulp = 2.0 ** -7 * ref.float().abs() + 1e-3
         assert float((d <= ulp).float().mean()) > 0.999 and bool((d <= 2 * ulp + 4e-3).all()), (N, K, float(d.max()))
+        # and against the oracle (fp64 products, one rounding) on sampled rows: first / last rows of the ragged last M-tile,
+        # rows around the batch boundary and random ones
+        rows = torch.cat([torch.tensor([0, 1, 255, 256, 17775, 17776, 17777, M - 225, M - 224, M - 2, M - 1]),
+                          torch.randint(0, M, (53,), generator=g)])
+        want = _oracle(x[rows.cuda()].cpu(), w.cpu(), b.cpu(), 0)
+        _check(first[rows.cuda()], want, scale=2.0)
         del x, w, b, ref, first, d, ulp
