@@ -1,6 +1,37 @@
-# In-kernel cycle stamps of the attention loop (s_memtime): loop total, LDS-write segment, barrier wait.
+# In-kernel cycle stamps (s_memtime) of the shipped attention loop: loop total, LDS-write segment, barrier wait, for
+# waves 0 and 7 of two workgroups.  Patches a COPY of attn_fwd.hip; timing-only build.  Usage on the GPU box:
+#   bash tools/exp_attn_stamp.sh
 cd $GRAFT_REPO_ROOT/trajectorycrafter_amd/csrc
-cp $GRAFT_REPO_ROOT/tools/exp/attn_stamp.hip.txt /tmp/attn_stamp.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -I. -x hip -c /tmp/attn_stamp.hip -o /tmp/attn_s.o && \
+python3 - <<'PY'
+s = open("attn_fwd.hip").read()
+s = s.replace("""#ifndef TCX_EXP_NOWRITE
+        write_k(J0, (PH + TPB + 1) % R);""", """        const long long tA = clock64();
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef TCX_EXP_NOWRITE
+        write_k(J0, (PH + TPB + 1) % R);""")
+s = s.replace("""#ifndef TCX_EXP_NOBARRIER
+        __syncthreads();
+#endif
+    };""", """        __builtin_amdgcn_sched_barrier(0);
+        const long long tB = clock64();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        const long long tC = clock64();
+        st_write += tB - tA;
+        st_bar += tC - tB;
+        st_n += 1;
+    };""")
+s = s.replace("    auto run = [&](auto bnd) __attribute__((always_inline)) {", "    const long long tRun0 = clock64();\n    auto run = [&](auto bnd) __attribute__((always_inline)) {")
+s = s.replace("    run(std::integral_constant<bool, BOUND>{});\n", """    run(std::integral_constant<bool, BOUND>{});
+    if (BOUND && (blockIdx.x == 100 || blockIdx.x == 3001) && lane == 0 && (wave == 0 || wave == 7))
+        printf("STAMP wg %d wave %d: loop %lld counts, %lld super-steps, write %lld, barrier %lld, tiles %d\\\\n", (int)blockIdx.x, wave,
+               (long long)(clock64() - tRun0), st_n, st_write, st_bar, ntiles);
+""")
+s = s.replace("    bf16x8 kfa[2], kfb[2];\n", "    long long st_write = 0, st_bar = 0, st_n = 0;\n    bf16x8 kfa[2], kfb[2];\n", 1)
+assert s.count("st_write") >= 3
+open("/tmp/attn_stamp.hip", "w").write(s)
+PY
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -w -I. -x hip -c /tmp/attn_stamp.hip -o /tmp/attn_s.o && \
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libtcx_s.so tcx_api.o /tmp/attn_s.o norm.o elementwise.o conv.o groupnorm.o warp.o gemm.o && \
-TCX_LIB=/tmp/libtcx_s.so python3 $GRAFT_REPO_ROOT/tools/microbench.py attn --iters 1 2>&1 | grep -v amdgpu.ids | grep "STAMP\|PP wg\|bound" | head -20
+TCX_LIB=/tmp/libtcx_s.so python3 $GRAFT_REPO_ROOT/tools/microbench.py attn --iters 1 2>&1 | grep "STAMP" | sort | uniq -c | sort -rn | head -8
