@@ -27,6 +27,24 @@ __global__ __launch_bounds__(512) void k(long long* out, float seed) {
         } else if constexpr (KIND == 3) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %0" : "+v"(a[i]));
+        } else if constexpr (KIND == 7) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_exp_f16 %0, %0" : "+v"(a[i]));
+        } else if constexpr (KIND == 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_exp_legacy_f32 %0, %0" : "+v"(a[i]));
+        } else if constexpr (KIND == 9) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+        } else if constexpr (KIND == 10) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a[i]));
+        } else if constexpr (KIND == 11) {
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(*(double*)&a[i]));
+        } else if constexpr (KIND == 12) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_ldexp_f32 %0, %0, 3" : "+v"(a[i]));
         } else if constexpr (KIND == 4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[j], 0, 0, 0);
@@ -76,6 +94,12 @@ int main() {
         run<1>("v_add_f32 x8", threads, 8);
         run<2>("v_pk_add_f32 x4", threads, 4);
         run<3>("v_cvt_pk_bf16_f32 x8", threads, 8);
+        run<7>("v_exp_f16 x8", threads, 8);
+        run<8>("v_exp_legacy_f32 x8", threads, 8);
+        run<9>("v_rcp_f32 x8", threads, 8);
+        run<10>("v_fma_f32 x8", threads, 8);
+        run<11>("v_pk_fma_f32 x4", threads, 4);
+        run<12>("v_ldexp_f32 x8", threads, 8);
         run<4>("mfma 32x32x16 bf16 x4 (indep)", threads, 4);
         run<5>("4 x {mfma, 2 exp, 2 add, cvt} per 'instr' = group", threads, 4);
     }
