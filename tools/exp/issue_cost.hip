@@ -45,6 +45,16 @@ __global__ __launch_bounds__(512) void k(long long* out, float seed) {
         } else if constexpr (KIND == 12) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) asm volatile("v_ldexp_f32 %0, %0, 3" : "+v"(a[i]));
+        } else if constexpr (KIND == 13) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(fa[0]), "v"(fb[0]));
+        } else if constexpr (KIND == 14) {      // group with one dot2 instead of two adds
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[j], 0, 0, 0);
+                asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_cvt_pk_bf16_f32 %4, %4, %4\n\tv_dot2_f32_bf16 %2, %4, %3, %2"
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]));
+            }
         } else if constexpr (KIND == 4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[j], 0, 0, 0);
@@ -100,6 +110,8 @@ int main() {
         run<10>("v_fma_f32 x8", threads, 8);
         run<11>("v_pk_fma_f32 x4", threads, 4);
         run<12>("v_ldexp_f32 x8", threads, 8);
+        run<13>("v_dot2_f32_bf16 x8", threads, 8);
+        run<14>("4 x {mfma, 2 exp, cvt, dot2} = group'", threads, 4);
         run<4>("mfma 32x32x16 bf16 x4 (indep)", threads, 4);
         run<5>("4 x {mfma, 2 exp, 2 add, cvt} per 'instr' = group", threads, 4);
     }
