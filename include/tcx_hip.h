@@ -116,6 +116,11 @@ int tcx_bias_gelu_tanh(const void* x, const void* bias, void* y, int64_t rows, i
 /* ---- elementwise helpers -------------------------------------------------------------------- */
 /* y = bf16(x * s): the q*scale / k*scale of PerceiverCrossAttention (crosstransformer3d.py:391-392). */
 int tcx_scale_bf16(const void* x, void* y, int64_t n, float s, void* stream);
+/* y[b,s,h,:] = bf16(x[b,s,h,:] * scale) (y contiguous [B,S,H,D]; x a [B,S,H*D] view with free batch / row strides, e.g. the
+ * k half of the to_kv output) and sqmax[b,h] = max_s |y[b,s,h,:]|^2: the k*scale of PerceiverCrossAttention (:392) fused with the
+ * bound input (k_sqmax) of tcx_attn_fwd's bound-centred loop.  D in {64, 128}.  sqmax: fp32 [B,H], zeroed by the call. */
+int tcx_scale_sqmax_bf16(const void* x, void* y, int32_t B, int32_t S, int32_t H, int32_t D, int64_t x_stride_b,
+                         int64_t x_stride_s, float scale, float* sqmax, void* stream);
 /* y = silu(x), bf16 -> bf16: the SiLU in front of every AdaLN linear (diffusers LayerNormZero/AdaLayerNorm). */
 int tcx_silu_bf16(const void* x, void* y, int64_t n, void* stream);
 

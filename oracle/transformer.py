@@ -52,6 +52,11 @@ def perceiver_cross_attention(p: Prec, sd: dict, prefix: str, x, latents, heads:
 
     q, k, v = split(q), split(k), split(v)
     s = 1.0 / (dim_head ** 0.25)
+    if p.mode == "bf16":                                            # HIP contract: q carries log2(e) too, base-2 softmax
+        qs, ks = p.R(q * (s * dr.LOG2E)), p.R(k * s)
+        o = p.R(dr.sdpa_log2(p, qs, ks, v))
+        o = o.permute(0, 2, 1, 3).reshape(B, S, -1)
+        return p.linear_fused(o, sd[prefix + "to_out.weight"])      # consumed by the caller's residual add
     qs, ks = p.R(q * s), p.R(k * s)
     if p.mode == "bf16_ref":
         w = p.r(torch.matmul(qs, ks.transpose(-1, -2)))          # the reference materialises bf16 scores (:392)

@@ -90,11 +90,11 @@ def test_attn_fwd_matches_oracle(ops, D, B, H, Sq, Sk):
 
 @pytest.mark.parametrize("B,H,Sq,Sk", [(1, 2, 300, 333), (2, 3, 513, 64), (1, 1, 1, 1), (1, 2, 70, 129), (1, 1, 256, 2048),
                                        (1, 1, 40, 128), (1, 2, 33, 100), (1, 1, 64, 300), (1, 1, 64, 449)])   # 2, 2, 5, 8 key tiles
-def test_attn_fwd_log2_scores_fast_path(ops, B, H, Sq, Sk):
-    """TCX_ATTN_LOG2_SCORES (D = 64): q pre-multiplied by scale*log2(e); running max as the MFMA initial
-    accumulator; row sum of the rounded P on the matrix pipe.  Oracle: dr.sdpa_log2."""
-    D = 64
-    g = torch.Generator().manual_seed(Sq + Sk)
+@pytest.mark.parametrize("D", [64, 128])
+def test_attn_fwd_log2_scores_fast_path(ops, B, H, Sq, Sk, D):
+    """TCX_ATTN_LOG2_SCORES (D = 64 and 128): q pre-multiplied by scale*log2(e); running max as the MFMA initial
+    accumulator.  Oracle: dr.sdpa_log2."""
+    g = torch.Generator().manual_seed(Sq + Sk + D)
     q, k, v = (bf(torch.randn(B, s, H, D, generator=g)) for s in (Sq, Sk, Sk))
     q = bf(q.float() * (D ** -0.5 * 1.4426950408889634))
     qt, kt, vt = q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)
@@ -140,12 +140,13 @@ def test_attn_fwd_fast_path_forced_recentre(ops):
     assert_attn_close(ob, ref, bound)
 
 
-def test_attn_fwd_bound_mixed_workgroups(ops):
+@pytest.mark.parametrize("D", [64, 128])
+def test_attn_fwd_bound_mixed_workgroups(ops, D):
     """Some 256-row workgroups safe (bound loop), one with a huge-norm query row (exact loop): every row correct."""
-    g = torch.Generator().manual_seed(23)
-    B, H, S, D = 1, 2, 700, 64
+    g = torch.Generator().manual_seed(23 + D)
+    B, H, S = 1, 2, 700
     q, k, v = (bf(torch.randn(B, S, H, D, generator=g)) for _ in range(3))
-    q = bf(q.float() * 0.18)
+    q = bf(q.float() * (0.18 if D == 64 else 0.12))
     q[0, 300, 1] *= 40.0                              # M = |q||k|max ~ 1.4*40*10 >> 60 for the workgroup of rows 256..511, head 1
     qt, kt, vt = q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)
     ref = dr.sdpa_log2(Prec("bf16"), qt, kt, vt).transpose(1, 2).contiguous()
@@ -286,6 +287,20 @@ def test_bias_gelu_tanh_scale_silu(ops):
     assert_bf16_close(ops.silu(dev(x)), F.silu(x.float()))
     odd = bf(torch.randn(1003, generator=g))
     assert_bf16_close(ops.silu(dev(odd)), F.silu(odd.float()))
+
+
+@pytest.mark.parametrize("D,H", [(128, 16), (64, 3)])
+def test_scale_sqmax(ops, D, H):
+    """k * scale of the cross-attention fused with max_s |k|^2 per (batch, head); input is the k half of a [B,S,2HD] buffer."""
+    g = torch.Generator().manual_seed(D + H)
+    B, S, s_ = 2, 77, 0.2973
+    kv = bf(torch.randn(B, S, 2 * H * D, generator=g) * 3)
+    kv[1, 40, 5 * D // 2: 5 * D // 2 + 8] = 50.0                       # a spike decides one head's maximum
+    y, sq = ops.scale_sqmax(dev(kv)[..., :H * D], s_, H, D)
+    want = (kv[..., :H * D].float() * s_).to(BF)
+    assert torch.equal(y.cpu(), want)                                 # one fp32 multiply, one rounding: bit exact
+    ref = (want.float() ** 2).view(B, S, H, D).sum(-1).amax(1)
+    torch.testing.assert_close(sq.cpu(), ref, rtol=1e-5, atol=0)      # exact up to fp32 summation order
 
 
 def test_patchify_unpatchify_bit_exact(ops):

@@ -107,7 +107,10 @@ def test_transformer_block_and_cross_attention_signatures(golden, gpu):
     ref_tok, lat = t["tap_ref_tokens"].to(BF), t["tap_block0_hidden"].to(BF)
     ca = model.perceiver_cross_attention[0](ref_tok.to(gpu), lat.to(gpu))
     rca = otr.perceiver_cross_attention(p, sdf, "perceiver_cross_attention.0.", ref_tok.float(), lat.float(), 2, 64)
-    _check(ca, rca)
+    # called without add_to_latents the projection is stored (one rounding); fused, it is not.  The kernel's bound-centred
+    # softmax and the oracle's max-centred one round every probability independently (kernel tests: 3 * 2^-9 bound), on
+    # top of five rounded stages: mean tolerance 3e-3 of the mean magnitude instead of the single-op 2e-3
+    _check(ca, p.R(rca), mean_tol=3e-3)
 
 
 def test_transformer_rejects_cpu_and_missing_conditioning(golden, gpu):

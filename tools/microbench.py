@@ -77,6 +77,12 @@ def main():
         kk = k.contiguous()
         ms = timeit(lambda: ops.attn_fwd(q, kk, v, 1.0), iters)
         report("cross-attn q[2,16,17550,128] kv[.,4050,.]", ms, flops=4.0 * Sv * Sr * 2048 * B)
+        ql = (q.float() * 0.12).to(BF)                                        # log2-domain scores of moderate size
+        ksq = (kk.float() ** 2).sum(-1).amax(1).contiguous()
+        ms = timeit(lambda: ops.attn_fwd(ql, kk, v, 1.0, log2_scores=True), iters)
+        report("  log2 scores (FAST loop)", ms, flops=4.0 * Sv * Sr * 2048 * B)
+        ms = timeit(lambda: ops.attn_fwd(ql, kk, v, 1.0, log2_scores=True, k_sqmax=ksq), iters)
+        report("  log2 scores + bound-centred", ms, flops=4.0 * Sv * Sr * 2048 * B)
     if "gemm" in which:
         x = rn(B * S, Dm)
         for name, N, K in (("qkv  3072->9216", 9216, 3072), ("out  3072->3072", 3072, 3072), ("ff1  3072->12288", 12288, 3072),

@@ -210,8 +210,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
                 if (!safe) return;
                 m = M;
                 first = false;
+                if constexpr (D != 128) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) minit[i] = -M;
+                    for (int i = 0; i < 16; ++i) minit[i] = -M;
+                }
             } else {
                 if (safe) return;
             }
@@ -222,8 +224,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     auto qk_init = [&](f32x16 (&s)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            if constexpr (FAST) s[t] = minit;      // S' = K Q^T - m straight out of the MFMA chain
-            else {
+            if constexpr (FAST && !(BOUND && D == 128)) s[t] = minit;      // S' = K Q^T - m straight out of the MFMA chain
+            else {                                 // (bound-centred D = 128: |S| <= M < 60, P = exp2(S) needs no centring at all)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s[t][i] = 0.f;
             }
@@ -691,11 +693,12 @@ extern "C" int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o
     p.qsb = qsb; p.qss = qss; p.qsh = qsh; p.ksb = ksb; p.kss = kss; p.ksh = ksh;
     p.vsb = vsb; p.vss = vss; p.vsh = vsh; p.osb = osb; p.oss = oss; p.osh = osh;
     p.scale_log2 = log2s ? 1.0f : scale * 1.4426950408889634f;
-    p.k_sqmax = (log2s && D == 64) ? k_sqmax : nullptr;
+    p.k_sqmax = log2s ? k_sqmax : nullptr;
     TCX_CHECK((uint64_t)((Sq + 127) / 128) * B * H < (1ull << 31), TCX_E_SHAPE, "tcx_attn_fwd: grid too large");
     p.nqb = 0; p.nwg = 0;       // set per launch geometry
     hipStream_t s = (hipStream_t)stream;
     if (D == 64 && log2s) return out_dtype == TCX_F32 ? launch<64, true, true>(p, s) : launch<64, false, true>(p, s);
     if (D == 64) return out_dtype == TCX_F32 ? launch<64, true, false>(p, s) : launch<64, false, false>(p, s);
+    if (D == 128 && log2s) return out_dtype == TCX_F32 ? launch<128, true, true>(p, s) : launch<128, false, true>(p, s);
     return out_dtype == TCX_F32 ? launch<128, true, false>(p, s) : launch<128, false, false>(p, s);
 }

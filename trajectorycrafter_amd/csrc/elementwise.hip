@@ -85,6 +85,38 @@ __global__ __launch_bounds__(256) void unary_kernel(const uint16_t* x, uint16_t*
     }
 }
 
+// y[b,s,h,:] = bf16(x[b,s,h,:] * scale) and sqmax[b,h] = max_s |y[b,s,h,:]|^2 (of the ROUNDED values): the k * scale of the
+// cross-attention plus the Cauchy-Schwarz input of the bound-centred attention loop.  D / 8 lanes per head vector.
+template <int LPV>
+__global__ __launch_bounds__(256) void scale_sqmax_kernel(const uint16_t* x, uint16_t* y, int64_t nvec, int32_t S, int32_t H, int64_t xsb,
+                                                          int64_t xss, float scale, float* sqmax) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t vec = gid / LPV;
+    const int sub = (int)(gid % LPV);
+    const bool active = vec < nvec;
+    const int64_t vv = active ? vec : 0;
+    const int h = (int)(vv % H);
+    const int64_t tok = vv / H;
+    const int b = (int)(tok / S), srow = (int)(tok - (int64_t)b * S);
+    float v[8], o[8], r[8];
+    unpack8(*reinterpret_cast<const u32x4*>(x + (int64_t)b * xsb + (int64_t)srow * xss + (int64_t)h * (LPV * 8) + 8 * sub), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = v[e] * scale;
+    const u32x4 packed = pack8(o);
+    if (active) *reinterpret_cast<u32x4*>(y + vv * (LPV * 8) + 8 * sub) = packed;
+    unpack8(packed, r);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(r[e], r[e], ss);
+#pragma unroll
+    for (int off = 1; off < LPV; off <<= 1) ss += __shfl_xor(ss, off, 64);
+    if (active && sub == 0) {
+        unsigned* dst = reinterpret_cast<unsigned*>(sqmax + (int64_t)b * H + h);
+        const unsigned bits = __float_as_uint(ss);            // non-negative floats order like their bit patterns
+        if (bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
+    }
+}
+
 // out[(b,f,gy,gx), (c,ky,kx)] = in[b,f,c, gy*p+ky, gx*p+kx], c over the concat of a (Ca ch) and b (Cb ch); rows are
 // ks >= K elements long, zero-filled past K (the GEMM wants K % 128 == 0)
 __global__ __launch_bounds__(256) void patchify_kernel(const uint16_t* a, const uint16_t* bsrc, uint16_t* out,
@@ -253,6 +285,23 @@ extern "C" int tcx_scale_bf16(const void* x, void* y, int64_t n, float s, void* 
     TCX_CHECK(n > 0, TCX_E_SHAPE, "tcx_scale_bf16: n must be positive");
     TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(y), TCX_E_ALIGN, "tcx_scale_bf16: pointers must be 16-byte aligned");
     hipLaunchKernelGGL(unary_kernel<0>, dim3(grid_for((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, n, s);
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_scale_sqmax_bf16(const void* x, void* y, int32_t B, int32_t S, int32_t H, int32_t D, int64_t x_stride_b,
+                                    int64_t x_stride_s, float scale, float* sqmax, void* stream) {
+    TCX_CHECK(x && y && sqmax, TCX_E_NULL, "tcx_scale_sqmax_bf16: null pointer");
+    TCX_CHECK(B > 0 && S > 0 && H > 0 && (D == 64 || D == 128), TCX_E_SHAPE, "tcx_scale_sqmax_bf16: bad shape B=%d S=%d H=%d D=%d", B, S, H, D);
+    TCX_CHECK(x_stride_s >= (int64_t)H * D && x_stride_b % 8 == 0 && x_stride_s % 8 == 0, TCX_E_ALIGN, "tcx_scale_sqmax_bf16: bad strides");
+    TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(y), TCX_E_ALIGN, "tcx_scale_sqmax_bf16: pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t me = hipMemsetAsync(sqmax, 0, sizeof(float) * (size_t)B * H, st);
+    if (me != hipSuccess) { tcx_set_error("tcx_scale_sqmax_bf16: memset failed: %s", hipGetErrorString(me)); return (int)me; }
+    const int64_t nvec = (int64_t)B * S * H, nthr = nvec * (D / 8);
+    const int64_t nblk = (nthr + 255) / 256;
+    TCX_CHECK(nblk < (1ll << 31), TCX_E_SHAPE, "tcx_scale_sqmax_bf16: grid too large");
+    if (D == 64) hipLaunchKernelGGL(scale_sqmax_kernel<8>, dim3((unsigned)nblk), dim3(256), 0, st, (const uint16_t*)x, (uint16_t*)y, nvec, S, H, x_stride_b, x_stride_s, scale, sqmax);
+    else hipLaunchKernelGGL(scale_sqmax_kernel<16>, dim3((unsigned)nblk), dim3(256), 0, st, (const uint16_t*)x, (uint16_t*)y, nvec, S, H, x_stride_b, x_stride_s, scale, sqmax);
     TCX_LAUNCH_RET();
 }
 

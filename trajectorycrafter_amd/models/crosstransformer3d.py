@@ -316,9 +316,12 @@ class PerceiverCrossAttention(nn.Module):
         q = _linear(ln, self.to_q.weight)                                                            # :384
         kv = _linear(xn, self.to_kv.weight)                                                          # :385
         k, v = kv.chunk(2, dim=-1)
-        q = ops.scale_bf16(q, s, out=q)                                                              # :392 (q * scale)
-        k = ops.scale_bf16(k.contiguous(), s)                                                        # :392 (k * scale)
-        o = ops.attn_fwd(q.view(B, Sv, H, dh), k.view(B, -1, H, dh), v.view(B, -1, H, dh), 1.0)      # :392-395
+        # :392: q * scale and k * scale, each rounded before QK^T.  q additionally carries log2(e) (one rounding, as in the
+        # self-attention) so that the attention kernel works on base-2 scores; k's pass also yields max |k|^2 per head, the
+        # bound of the bound-centred loop (1068 vs 913 TF for the exact-tracking loop on this shape)
+        q = ops.scale_bf16(q, s * LOG2E, out=q)
+        k, ksq = ops.scale_sqmax(k, s, H, dh)
+        o = ops.attn_fwd(q.view(B, Sv, H, dh), k.view(B, -1, H, dh), v.view(B, -1, H, dh), 1.0, log2_scores=True, k_sqmax=ksq)   # :392-395
         if add_to_latents:
             return _linear(o.view(B, Sv, H * dh), self.to_out.weight, None, ops.GEMM_GATED_RESIDUAL, res=latents)
         return _linear(o.view(B, Sv, H * dh), self.to_out.weight)                                   # :397-398

@@ -180,6 +180,20 @@ def scale_bf16(x: torch.Tensor, s: float, out: Optional[torch.Tensor] = None) ->
     return out
 
 
+def scale_sqmax(x: torch.Tensor, s: float, H: int, D: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x: [B, S, H*D] bf16 view (unit inner stride, free row / batch strides) -> (y = bf16(x * s) contiguous [B,S,H*D],
+    sqmax fp32 [B,H] = max over rows of |y[b,s,h,:]|^2): k * scale of the cross-attention + attn_fwd's k_sqmax in one pass."""
+    _need(x, "x")
+    if x.dim() != 3 or x.shape[2] != H * D or x.stride(2) != 1:
+        raise TcxError(f"scale_sqmax: expected a [B,S,{H * D}] view with unit inner stride, got {tuple(x.shape)} / {x.stride()}")
+    B, S, _ = x.shape
+    y = torch.empty((B, S, H * D), device=x.device, dtype=BF16)
+    sq = torch.empty((B, H), device=x.device, dtype=torch.float32)
+    check(_lib.load().tcx_scale_sqmax_bf16(_p(x), _p(y), B, S, H, D, x.stride(0), x.stride(1), float(s), _p(sq), _stream()),
+          "tcx_scale_sqmax_bf16")
+    return y, sq
+
+
 def silu(x: torch.Tensor) -> torch.Tensor:
     _need(x, "x")
     x = x.contiguous()
