@@ -83,6 +83,8 @@ def main():
         report("  log2 scores (FAST loop)", ms, flops=4.0 * Sv * Sr * 2048 * B)
         ms = timeit(lambda: ops.attn_fwd(ql, kk, v, 1.0, log2_scores=True, k_sqmax=ksq), iters)
         report("  log2 scores + bound-centred", ms, flops=4.0 * Sv * Sr * 2048 * B)
+        ms = timeit(lambda: ops.scale_sqmax(kv[..., :2048], 0.2973, 16, 128), iters)
+        report("  k * scale + max|k|^2 [2,4050,2048]", ms, bytes_=2.0 * B * Sr * 2048 * 2)
     if "gemm" in which:
         x = rn(B * S, Dm)
         for name, N, K in (("qkv  3072->9216", 9216, 3072), ("out  3072->3072", 3072, 3072), ("ff1  3072->12288", 12288, 3072),

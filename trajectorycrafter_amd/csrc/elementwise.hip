@@ -87,32 +87,48 @@ __global__ __launch_bounds__(256) void unary_kernel(const uint16_t* x, uint16_t*
 
 // y[b,s,h,:] = bf16(x[b,s,h,:] * scale) and sqmax[b,h] = max_s |y[b,s,h,:]|^2 (of the ROUNDED values): the k * scale of the
 // cross-attention plus the Cauchy-Schwarz input of the bound-centred attention loop.  D / 8 lanes per head vector.
+// A wave owns 64 / LPV heads of one batch item and walks kTokPerWave rows: the running max stays in registers and
+// costs one atomic per head and wave (per-vector atomics on B*H addresses made the first version 7x slower than the copy).
+constexpr int kTokPerWave = 32;
 template <int LPV>
-__global__ __launch_bounds__(256) void scale_sqmax_kernel(const uint16_t* x, uint16_t* y, int64_t nvec, int32_t S, int32_t H, int64_t xsb,
+__global__ __launch_bounds__(256) void scale_sqmax_kernel(const uint16_t* x, uint16_t* y, int32_t S, int32_t H, int64_t xsb,
                                                           int64_t xss, float scale, float* sqmax) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t vec = gid / LPV;
-    const int sub = (int)(gid % LPV);
-    const bool active = vec < nvec;
-    const int64_t vv = active ? vec : 0;
-    const int h = (int)(vv % H);
-    const int64_t tok = vv / H;
-    const int b = (int)(tok / S), srow = (int)(tok - (int64_t)b * S);
-    float v[8], o[8], r[8];
-    unpack8(*reinterpret_cast<const u32x4*>(x + (int64_t)b * xsb + (int64_t)srow * xss + (int64_t)h * (LPV * 8) + 8 * sub), v);
+    constexpr int HPW = 64 / LPV;                       // heads per wave
+    const int lane = threadIdx.x & 63, sub = lane % LPV, hl = lane / LPV;
+    const int hgroups = (H + HPW - 1) / HPW;
+    const int b = blockIdx.z, hg = blockIdx.y;
+    const int h = hg * HPW + hl;
+    const bool hok = h < H;
+    const int s0 = ((int)blockIdx.x * 4 + (threadIdx.x >> 6)) * kTokPerWave;
+    (void)hgroups;
+    float best = 0.f;
+    const int hc = hok ? h : H - 1;
+    const uint16_t* xb = x + (int64_t)b * xsb + (int64_t)hc * (LPV * 8) + 8 * sub;
+    for (int sbase = s0; sbase < S && sbase < s0 + kTokPerWave; sbase += 4) {      // four rows in flight per lane
+        u32x4 raw[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = v[e] * scale;
-    const u32x4 packed = pack8(o);
-    if (active) *reinterpret_cast<u32x4*>(y + vv * (LPV * 8) + 8 * sub) = packed;
-    unpack8(packed, r);
-    float ss = 0.f;
+        for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const u32x4*>(xb + (int64_t)min(sbase + u, S - 1) * xss);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(r[e], r[e], ss);
+        for (int u = 0; u < 4; ++u) {
+            const int srow = sbase + u;
+            float v[8], o[8], r[8];
+            unpack8(raw[u], v);
 #pragma unroll
-    for (int off = 1; off < LPV; off <<= 1) ss += __shfl_xor(ss, off, 64);
-    if (active && sub == 0) {
+            for (int e = 0; e < 8; ++e) o[e] = v[e] * scale;
+            const u32x4 packed = pack8(o);
+            if (hok && srow < S) *reinterpret_cast<u32x4*>(y + (((int64_t)b * S + srow) * H + h) * (LPV * 8) + 8 * sub) = packed;
+            unpack8(packed, r);
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(r[e], r[e], ss);
+#pragma unroll
+            for (int off = 1; off < LPV; off <<= 1) ss += __shfl_xor(ss, off, 64);
+            if (srow < S) best = fmaxf(best, ss);
+        }
+    }
+    if (hok && sub == 0 && s0 < S) {
         unsigned* dst = reinterpret_cast<unsigned*>(sqmax + (int64_t)b * H + h);
-        const unsigned bits = __float_as_uint(ss);            // non-negative floats order like their bit patterns
+        const unsigned bits = __float_as_uint(best);          // non-negative floats order like their bit patterns
         if (bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
     }
 }
@@ -297,11 +313,11 @@ extern "C" int tcx_scale_sqmax_bf16(const void* x, void* y, int32_t B, int32_t S
     hipStream_t st = (hipStream_t)stream;
     hipError_t me = hipMemsetAsync(sqmax, 0, sizeof(float) * (size_t)B * H, st);
     if (me != hipSuccess) { tcx_set_error("tcx_scale_sqmax_bf16: memset failed: %s", hipGetErrorString(me)); return (int)me; }
-    const int64_t nvec = (int64_t)B * S * H, nthr = nvec * (D / 8);
-    const int64_t nblk = (nthr + 255) / 256;
-    TCX_CHECK(nblk < (1ll << 31), TCX_E_SHAPE, "tcx_scale_sqmax_bf16: grid too large");
-    if (D == 64) hipLaunchKernelGGL(scale_sqmax_kernel<8>, dim3((unsigned)nblk), dim3(256), 0, st, (const uint16_t*)x, (uint16_t*)y, nvec, S, H, x_stride_b, x_stride_s, scale, sqmax);
-    else hipLaunchKernelGGL(scale_sqmax_kernel<16>, dim3((unsigned)nblk), dim3(256), 0, st, (const uint16_t*)x, (uint16_t*)y, nvec, S, H, x_stride_b, x_stride_s, scale, sqmax);
+    const int lpv = D / 8, hpw = 64 / lpv;
+    TCX_CHECK(B <= 65535 && (H + hpw - 1) / hpw <= 65535, TCX_E_SHAPE, "tcx_scale_sqmax_bf16: B / H exceed the grid limits");
+    const dim3 grid((unsigned)((S + 4 * kTokPerWave - 1) / (4 * kTokPerWave)), (unsigned)((H + hpw - 1) / hpw), (unsigned)B);
+    if (D == 64) hipLaunchKernelGGL(scale_sqmax_kernel<8>, grid, dim3(256), 0, st, (const uint16_t*)x, (uint16_t*)y, S, H, x_stride_b, x_stride_s, scale, sqmax);
+    else hipLaunchKernelGGL(scale_sqmax_kernel<16>, grid, dim3(256), 0, st, (const uint16_t*)x, (uint16_t*)y, S, H, x_stride_b, x_stride_s, scale, sqmax);
     TCX_LAUNCH_RET();
 }
 
