@@ -215,7 +215,7 @@ int tcx_cl_to_ncthw_frames(const void* x, float* y, int32_t N, int32_t C, int64_
  *       gate[b] = gate_x + b * gate_stride_b; both gates null -> gate = 1 (the plain residual of :833-837).
  * x rows are uniformly strided (ldx).  With rows_per_batch > 0, y and res are [B, rows_per_batch, N] views: row m =
  * (b, r) lives at y + b * y_stride_b + r * ldy (a row range of the joint text+video buffer); with 0 they are flat.
- * Needs N % 8 == 0, K % 128 == 0, ldx % 8 == 0, ldy % 4 == 0; any M.  256 x 256 output tiles (ragged edges are
+ * Needs N % 8 == 0, K % 128 == 0, ldx % 8 == 0, ldy % 8 == 0 (16-byte row-wise stores); any M.  256 x 256 output tiles (ragged edges are
  * masked), 128 KiB of LDS per workgroup. */
 #define TCX_GEMM_BIAS 0
 #define TCX_GEMM_BIAS_GELU 1

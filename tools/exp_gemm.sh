@@ -2,7 +2,7 @@
 # Usage on the GPU box: bash tools/exp_gemm.sh
 cd $GRAFT_REPO_ROOT/trajectorycrafter_amd/csrc
 i=0
-for extra in "" "-DTCX_GEMM_EXP_PEEL" "" "-DTCX_GEMM_EXP_PEEL"; do
+for extra in "" "-DTCX_GEMM_EXP_DIRECT_RES" "" "-DTCX_GEMM_EXP_DIRECT_RES"; do
   i=$((i+1))
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off $extra -x hip -c gemm.hip -o /tmp/gemm_$i.o && \
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libtcx_$i.so tcx_api.o attn_fwd.o norm.o elementwise.o conv.o groupnorm.o warp.o /tmp/gemm_$i.o && \

@@ -273,19 +273,48 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
             rbb[a] = m;
             if (p.rows_per_batch > 0) { bb[a] = m / (uint32_t)p.rows_per_batch; rbb[a] = m - bb[a] * (uint32_t)p.rows_per_batch; }
         }
-        // all 32 residual vectors of the lane in flight at once (the fragment registers of the main loop are free now)
+        // residual: all of the lane's vectors in flight at once (the fragment registers of the main loop are free now).
+        // Default: fetched ROW-WISE (16 instructions of 8 rows x 128 B, 16 bytes per lane) into the wave's LDS tile, the
+        // same image the result is written back through, and picked up from there in the accumulator layout.
+#if defined(TCX_GEMM_EXP_DIRECT_STORE) || defined(TCX_GEMM_EXP_DIRECT_RES)
         u32x2 rv[8][4];
+#endif
         if constexpr (EPI == 2) {
+#if defined(TCX_GEMM_EXP_DIRECT_STORE) || defined(TCX_GEMM_EXP_DIRECT_RES)
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
                 const uint16_t* rrow = p.res + (int64_t)bb[a] * p.res_stride_b + (int64_t)rbb[a] * p.ldres;
 #pragma unroll
                 for (int bq = 0; bq < 4; ++bq) rv[a][bq] = *reinterpret_cast<const u32x2*>(rrow + ncol[bq]);
             }
+#else
+            {
+                const int rl = lane >> 3, ch = lane & 7;
+                int nc8 = n0 + wc * 64 + ch * 8;
+                nc8 = nc8 < p.N ? nc8 : p.N - 8;
+                u32x4 rr[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    uint32_t m = (uint32_t)m0 + wr * 128 + i * 8 + rl;
+                    m = m < (uint32_t)p.M ? m : (uint32_t)p.M - 1;
+                    uint32_t b = 0, rb = m;
+                    if (p.rows_per_batch > 0) { b = m / (uint32_t)p.rows_per_batch; rb = m - b * (uint32_t)p.rows_per_batch; }
+                    rr[i] = *reinterpret_cast<const u32x4*>(p.res + (int64_t)b * p.res_stride_b + (int64_t)rb * p.ldres + nc8);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = i * 8 + rl;
+                    *reinterpret_cast<u32x4*>(lds + wid * 16384 + row * 128 + ((ch ^ (row & 7)) << 4)) = rr[i];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile now holds the residual; each element is read
+            }                                                        // and then overwritten with its result by the same lane
+#endif
         }
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
+#ifdef TCX_GEMM_EXP_DIRECT_STORE
             uint16_t* yrow = p.y + (int64_t)bb[a] * p.y_stride_b + (int64_t)rbb[a] * p.ldy;
+#endif
             u32x2 gv[4];
             if constexpr (EPI == 2 && GATED) {
                 const uint16_t* gate = (rbb[a] < (uint32_t)p.text_len ? p.gate_t : p.gate_v) + (int64_t)bb[a] * p.gate_stride_b;
@@ -302,7 +331,13 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
                     for (int j = 0; j < 4; ++j) v[j] = gelu_tanh_f(v[j]);
                 }
                 if constexpr (EPI == 2) {
-                    const float r[4] = {bf16lo(rv[a][bq][0]), bf16hi(rv[a][bq][0]), bf16lo(rv[a][bq][1]), bf16hi(rv[a][bq][1])};
+#if defined(TCX_GEMM_EXP_DIRECT_STORE) || defined(TCX_GEMM_EXP_DIRECT_RES)
+                    const u32x2 rvv = rv[a][bq];
+#else
+                    const u32x2 rvv = *reinterpret_cast<const u32x2*>(lds + wid * 16384 + (a * 16 + fi) * 128 +
+                                                                      (((bq * 2 + (fg >> 1)) ^ ((a * 16 + fi) & 7)) << 4) + ((fg & 1) << 3));
+#endif
+                    const float r[4] = {bf16lo(rvv[0]), bf16hi(rvv[0]), bf16lo(rvv[1]), bf16hi(rvv[1])};
                     if constexpr (GATED) {
                         const float gg[4] = {bf16lo(gv[bq][0]), bf16hi(gv[bq][0]), bf16lo(gv[bq][1]), bf16hi(gv[bq][1])};
 #pragma unroll
@@ -315,9 +350,35 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
                 u32x2 o;
                 o[0] = pack_bf16(v[0], v[1]);
                 o[1] = pack_bf16(v[2], v[3]);
+#ifdef TCX_GEMM_EXP_DIRECT_STORE
                 if (mok[a] && nok[bq]) *reinterpret_cast<u32x2*>(yrow + ncol[bq]) = o;
+#else
+                // through the wave's own 16 KiB of LDS (128 rows x 128 B; the main loop's buffers are free: every wave is past
+                // its last fragment read after the final barrier): 16-byte chunk c of row r sits at chunk c ^ (r & 7)
+                const int row = a * 16 + fi, chunk = bq * 2 + (fg >> 1);
+                *reinterpret_cast<u32x2*>(lds + wid * 16384 + row * 128 + ((chunk ^ (row & 7)) << 4) + ((fg & 1) << 3)) = o;
+#endif
             }
         }
+#ifndef TCX_GEMM_EXP_DIRECT_STORE
+        (void)mok;
+        // read back row-wise: one instruction = 8 rows x 128 B, full cache lines, 16-byte stores (the direct form was 32 stores
+        // of 8 bytes per lane, each instruction touching 16 rows x 32 B: store-issue bound)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int rl = lane >> 3, ch = lane & 7;
+        const int ncol8 = n0 + wc * 64 + ch * 8;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = i * 8 + rl;
+            const u32x4 val = *reinterpret_cast<const u32x4*>(lds + wid * 16384 + row * 128 + ((ch ^ (row & 7)) << 4));
+            const uint32_t m = (uint32_t)m0 + wr * 128 + row;
+            if (m < (uint32_t)p.M && ncol8 < p.N) {
+                uint32_t b = 0, rb = m;
+                if (p.rows_per_batch > 0) { b = m / (uint32_t)p.rows_per_batch; rb = m - b * (uint32_t)p.rows_per_batch; }
+                *reinterpret_cast<u32x4*>(p.y + (int64_t)b * p.y_stride_b + (int64_t)rb * p.ldy + ncol8) = val;
+            }
+        }
+#endif
     };
     if (EPI == 2 && p.gate_v) store_rows(std::true_type{});
     else store_rows(std::false_type{});
@@ -345,7 +406,7 @@ extern "C" int tcx_gemm_bf16(const void* x, const void* w, const void* bias, voi
     TCX_CHECK(M < (1ll << 31), TCX_E_SHAPE, "tcx_gemm_bf16: M=%lld exceeds 2^31 rows", (long long)M);
     TCX_CHECK(M > 0 && N > 0 && K > 0, TCX_E_SHAPE, "tcx_gemm_bf16: empty shape M=%lld N=%d K=%d", (long long)M, N, K);
     TCX_CHECK(N % 8 == 0 && K % (2 * BK) == 0, TCX_E_SHAPE, "tcx_gemm_bf16: needs N %% 8 == 0 and K %% 128 == 0 (N=%d K=%d)", N, K);
-    TCX_CHECK(ldx >= K && ldy >= N && ldx % 8 == 0 && ldy % 4 == 0, TCX_E_SHAPE, "tcx_gemm_bf16: bad leading dimensions ldx=%lld ldy=%lld", (long long)ldx, (long long)ldy);
+    TCX_CHECK(ldx >= K && ldy >= N && ldx % 8 == 0 && ldy % 8 == 0, TCX_E_SHAPE, "tcx_gemm_bf16: bad leading dimensions ldx=%lld ldy=%lld", (long long)ldx, (long long)ldy);
     TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(w) && tcx_aligned16(y) && tcx_aligned16(bias), TCX_E_ALIGN, "tcx_gemm_bf16: pointers must be 16-byte aligned");
     TCX_CHECK(epilogue >= 0 && epilogue <= 2, TCX_E_SHAPE, "tcx_gemm_bf16: unknown epilogue %d", epilogue);
     const int64_t mt = (M + BM - 1) / BM;
@@ -357,11 +418,11 @@ extern "C" int tcx_gemm_bf16(const void* x, const void* w, const void* bias, voi
     TCX_CHECK(rows_per_batch >= 0 && (rows_per_batch == 0 || M % rows_per_batch == 0), TCX_E_SHAPE,
               "tcx_gemm_bf16: M=%lld is not a multiple of rows_per_batch=%d", (long long)M, rows_per_batch);
     TCX_CHECK(rows_per_batch > 0 || y_stride_b == 0, TCX_E_SHAPE, "tcx_gemm_bf16: y_stride_b needs rows_per_batch");
-    TCX_CHECK(y_stride_b % 4 == 0 && res_stride_b % 4 == 0, TCX_E_ALIGN, "tcx_gemm_bf16: batch strides must be multiples of 4 elements");
+    TCX_CHECK(y_stride_b % 8 == 0 && res_stride_b % 8 == 0, TCX_E_ALIGN, "tcx_gemm_bf16: batch strides must be multiples of 4 elements");
     p.rows_per_batch = rows_per_batch; p.y_stride_b = rows_per_batch > 0 ? y_stride_b : 0;
     if (epilogue == TCX_GEMM_GATED_RESIDUAL) {
         TCX_CHECK(res, TCX_E_NULL, "tcx_gemm_bf16: the gated-residual epilogue needs res");
-        TCX_CHECK(ldres >= N && ldres % 4 == 0 && tcx_aligned16(res), TCX_E_SHAPE, "tcx_gemm_bf16: bad res layout");
+        TCX_CHECK(ldres >= N && ldres % 8 == 0 && tcx_aligned16(res), TCX_E_SHAPE, "tcx_gemm_bf16: bad res layout");
         TCX_CHECK((gate_v == nullptr) == (gate_t == nullptr), TCX_E_NULL, "tcx_gemm_bf16: give both gates or none");
         if (gate_v) {
             TCX_CHECK(rows_per_batch > 0 && text_len >= 0 && text_len <= rows_per_batch && gate_stride_b % 4 == 0,
