@@ -618,11 +618,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     const float inv = 1.0f / l;
     const int qrow = q0 + r;
 #ifndef TCX_EXP_DIRECT_OSTORE
-    if constexpr (!OUT_F32 && D == 64) {
-        // bf16 output through the wave's own 4 KiB of LDS (32 rows x 128 B, 16-byte chunk c of row q at c ^ (q & 7)) so that
-        // it leaves as 4 instructions of 8 rows x 128 B instead of 8 scattered 8-byte stores per lane (store-issue bound)
+    if constexpr (!OUT_F32) {
+        // bf16 output through the wave's own 32 x (2 D)-byte LDS tile (16-byte chunk c of row q at c ^ (q & 7)) so that it
+        // leaves as row-wise 16-byte stores (full lines) instead of 4 DT scattered 8-byte stores per lane (store-issue bound)
+        constexpr int RB = D * 2, CPR = D / 8, RPI = 64 / CPR;      // row bytes, chunks per row, rows per store instruction
         __syncthreads();                               // every wave is past its last K / V fragment read
-        char* ot = smem + wave * 4096;
+        char* ot = smem + wave * (32 * RB);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -631,14 +632,14 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
                 u32x2 w;
                 w[0] = pack_bf16(o[dt][4 * i] * inv, o[dt][4 * i + 1] * inv);
                 w[1] = pack_bf16(o[dt][4 * i + 2] * inv, o[dt][4 * i + 3] * inv);
-                *reinterpret_cast<u32x2*>(ot + r * 128 + (((d0 >> 3) ^ (r & 7)) << 4) + ((d0 & 4) << 1)) = w;
+                *reinterpret_cast<u32x2*>(ot + r * RB + (((d0 >> 3) ^ (r & 7)) << 4) + ((d0 & 4) << 1)) = w;
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int rl = lane >> 3, ch = lane & 7;
+        const int rl = lane / CPR, ch = lane % CPR;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 8 + rl;
-            const u32x4 val = *reinterpret_cast<const u32x4*>(ot + row * 128 + ((ch ^ (row & 7)) << 4));
+        for (int i = 0; i < 32 / RPI; ++i) {
+            const int row = i * RPI + rl;
+            const u32x4 val = *reinterpret_cast<const u32x4*>(ot + row * RB + ((ch ^ (row & 7)) << 4));
             const int qr = q0 + row;
             if (qr < p.Sq)
                 *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.osb + (int64_t)qr * p.oss + (int64_t)hd * p.osh + 8 * ch) = val;
