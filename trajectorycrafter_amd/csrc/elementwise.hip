@@ -121,8 +121,7 @@ __global__ __launch_bounds__(256) void scale_sqmax_kernel(const uint16_t* x, uin
             float ss = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(r[e], r[e], ss);
-#pragma unroll
-            for (int off = 1; off < LPV; off <<= 1) ss += __shfl_xor(ss, off, 64);
+            ss = LPV == 8 ? group8_sum(ss) : group16_sum(ss);
             if (srow < S) best = fmaxf(best, ss);
         }
     }

@@ -215,9 +215,7 @@ __global__ __launch_bounds__(256) void qk_ln_rope_kernel(const QkParams p) {
     float sum = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) sum += x[e];
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
-    sum += __shfl_xor(sum, 4, 64);
+    sum = group8_sum(sum);
     const float mean = sum * (1.0f / 64.0f);
     float sq = 0.f;
 #pragma unroll
@@ -225,9 +223,7 @@ __global__ __launch_bounds__(256) void qk_ln_rope_kernel(const QkParams p) {
         const float d = x[e] - mean;
         sq += d * d;
     }
-    sq += __shfl_xor(sq, 1, 64);
-    sq += __shfl_xor(sq, 2, 64);
-    sq += __shfl_xor(sq, 4, 64);
+    sq = group8_sum(sq);
     const float rstd = rsqrtf(sq * (1.0f / 64.0f) + p.eps);
     float g[8], be[8];
     unpack8(*reinterpret_cast<const u32x4*>((which ? p.gk : p.gq) + 8 * sub), g);
@@ -262,9 +258,7 @@ __global__ __launch_bounds__(256) void qk_ln_rope_kernel(const QkParams p) {
         float ss = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(r[e], r[e], ss);
-        ss += __shfl_xor(ss, 1, 64);
-        ss += __shfl_xor(ss, 2, 64);
-        ss += __shfl_xor(ss, 4, 64);
+        ss = group8_sum(ss);
         if (active && which && sub == 0) {
             unsigned* dst = reinterpret_cast<unsigned*>(p.k_sqmax + (int64_t)b * p.H + hh);
             const unsigned bits = __float_as_uint(ss);            // non-negative floats order like their bit patterns
@@ -330,9 +324,7 @@ __global__ __launch_bounds__(256) void qk_ln_rope_tok_kernel(const QkParams p) {
                 float sum = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sum += x[e];
-                sum += __shfl_xor(sum, 1, 64);
-                sum += __shfl_xor(sum, 2, 64);
-                sum += __shfl_xor(sum, 4, 64);
+                sum = group8_sum(sum);
                 const float mean = sum * (1.0f / 64.0f);
                 float sq = 0.f;
 #pragma unroll
@@ -340,9 +332,7 @@ __global__ __launch_bounds__(256) void qk_ln_rope_tok_kernel(const QkParams p) {
                     const float d = x[e] - mean;
                     sq += d * d;
                 }
-                sq += __shfl_xor(sq, 1, 64);
-                sq += __shfl_xor(sq, 2, 64);
-                sq += __shfl_xor(sq, 4, 64);
+                sq = group8_sum(sq);
                 const float rstd = rsqrtf(sq * (1.0f / 64.0f) + p.eps);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y[e] = (x[e] - mean) * rstd * g[e] + be[e];
@@ -369,9 +359,7 @@ __global__ __launch_bounds__(256) void qk_ln_rope_tok_kernel(const QkParams p) {
                     float ss = 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(r[e], r[e], ss);
-                    ss += __shfl_xor(ss, 1, 64);
-                    ss += __shfl_xor(ss, 2, 64);
-                    ss += __shfl_xor(ss, 4, 64);
+                    ss = group8_sum(ss);
                     kmax[i] = fmaxf(kmax[i], ss);
                 }
             }

@@ -64,9 +64,40 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
     return v;
 }
 
+
+// Sum over aligned groups of 8 (or 16) lanes with DPP moves (plain VALU) instead of __shfl_xor (ds_bpermute: an LDS round
+// trip and a wait per step).  After the two quad steps every lane of a quad holds the quad's sum, so the half-row /
+// row mirrors only have to reach ANY lane of the other quad / half: the result is bit-identical to the xor-1,2,4(,8) tree.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float group8_sum(float v) {
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror: lane i <-> 7 - i of each 8-lane half row
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+    v = group8_sum(v);
+    v += dpp_move<0x140>(v);     // row_mirror: lane i <-> 15 - i of each 16-lane row
+    return v;
+}
+
+// Sum over the 64 lanes, result in every lane: DPP inside rows of 16, then v_permlane16_swap / v_permlane32_swap (gfx950)
+// between rows — no LDS round trips (the __shfl_xor form is six ds_bpermute + waits).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = group16_sum(v);
+    {   // rows 0<->1 and 2<->3: after the swap the pair (a, b) holds this row's and the partner row's sums
+        const uint32_t u = __float_as_uint(v);
+        auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    {
+        const uint32_t u = __float_as_uint(v);
+        auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
     return v;
 }
 
