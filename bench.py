@@ -2,61 +2,103 @@
 """Headline benchmark: denoised video-latents/sec at 49 frames, 480x720 (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one whole clip of BASELINE configs[2] ("Full 50-step DDIM, 49-frame 480x720, random-init
-weights, 1 MI355X + MAGViT VAE decode"): 50 denoising steps with classifier-free guidance (each a B=2
-forward of the 42-block / 6.1 B-parameter CrossTransformer3DModel + the fused CFG/DDIM update) followed
-by the VAE decode to 49 frames.  Nothing is skipped or cached inside the timed region.  Inputs
-(latents, prompt embeddings, inpaint / reference latents) are synthetic and already resident in HBM.
-With N > 1 every rank denoises its own independent trajectory (weak scaling, no data-path collective)
-and one RCCL all-gather reassembles the decoded frames at the end of every step.
+Workload = BASELINE configs[2] ("Full 50-step DDIM, 49-frame 480x720, random-init weights, 1 MI355X + MAGViT VAE
+decode") on every GPU.  One **step** = one classifier-free-guidance denoising step of that clip at full size — the
+reference's loop body, models/pipeline_trajectorycrafter.py:1093-1178: a B=2 forward of the 42-block / 6.1 B-parameter
+CrossTransformer3DModel (S = 17 776 tokens) + the fused CFG / DDIM update — executed by the product entry point
+`TrajCrafter_Pipeline.denoise_step`; nothing is skipped or cached.  After W untimed warm-up steps exactly K steps are
+timed between barrier + synchronize pairs (max over ranks).  The steps are consecutive steps of ONE real trajectory
+(timesteps 999, 979, ...), so the data the kernels see is what a clip produces.  Then ONE full VAE decode of the
+latents (13 latent frames -> 49 frames 480x720) is timed the same way, and for N > 1 the single RCCL all-gather of the path
+(the decoder's bf16 output, 102 MB per rank).  A clip is 50 steps + 1 decode (+ 1 gather), hence
 
-Rank 0 prints ONE JSON line (see the driver contract) including
-  "roofline"     — the dominant kernel (self-attention, tcx_attn_fwd D=64): algorithmic FLOP per launch
-                   / average launch duration measured live with HIP events on the launch stream;
-  "cpu_baseline" — the oracle (CPU port of the reference) timed on the host cores on a bounded sample.
+    value = n_gpus / (50 * step_s + decode_s + gather_s)          [video-latents/s, whole job]
+
+with every term measured in this run and printed in `config` (a whole 50-step clip takes ~31 s, which is why a step is
+not a clip: the driver runs --steps 20 --warmup 5 under a 600 s limit).  Inputs (latents, prompt embeddings, inpaint /
+reference latents) are synthetic and resident in HBM before the timed region.
+
+N > 1: one process per GPU.  Started by torchrun (RANK / WORLD_SIZE in the environment) each process is one rank; started
+plainly as `python bench.py --gpus N`, this process launches `python -m torch.distributed.run --nproc-per-node N bench.py
+...` itself BEFORE touching the GPU and relays its output.  Every rank denoises its own independent trajectory (weak
+scaling, seeds 43 + rank as in inference_orbits.py:274-300); there is no collective inside the denoising.
+
+Rank 0 prints ONE JSON line (driver contract) with
+  "roofline"     - the dominant kernel (self-attention, tcx_attn_fwd D=64): algorithmic FLOP per launch / average launch
+                   duration measured live with HIP events on the launch stream over the timed steps;
+  "cpu_baseline" - the oracle (CPU port of the reference) timed on the host cores on a bounded sample (<= 30 s).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BF16 = torch.bfloat16
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md; 2:1-sparsity figures never used)
+CPU_BASELINE_BUDGET_S = 30.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1, help="timed clips per rank")
-    ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up clips per rank")
-    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=10, help="timed CFG denoising steps per rank")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up steps per rank")
+    ap.add_argument("--denoise-steps", type=int, default=50, help="steps of a clip (the clip-time formula and the DDIM schedule)")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=720)
     ap.add_argument("--frames", type=int, default=49)
     ap.add_argument("--layers", type=int, default=42, help="(debug) fewer layers => NOT the benchmark config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="(debug) skip the VAE decode => NOT the benchmark config")
-    return ap.parse_args()
+    ap.add_argument("--graph", type=int, default=None, help="1/0: replay the transformer forward from a hipGraph (default: the pipeline's default)")
+    ap.add_argument("--selftest-dist", action="store_true",
+                    help="(CPU test hook) run only the launcher + rank plumbing on gloo, no GPU, no model")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------- launcher (N > 1, no GPU use)
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_command(n: int, argv, port: int):
+    """The torchrun line this process starts for `python bench.py --gpus N ...` (the one the driver itself uses for N > 1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(args, argv) -> int:
+    """Start N fresh rank processes (children; this parent never initialises the GPU) and exit with their code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: required for RCCL on this pool
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = launch_command(args.gpus, argv, _free_port())
+    print("[bench] launching", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------- model + inputs
 def build_models(args, device):
+    import torch
     from trajectorycrafter_amd import init_weights as iw
     from trajectorycrafter_amd.models.autoencoder_magvit import AutoencoderKLCogVideoX
     from trajectorycrafter_amd.models.crosstransformer3d import CrossTransformer3DModel
     from trajectorycrafter_amd.models.pipeline_trajectorycrafter import TrajCrafter_Pipeline
     from trajectorycrafter_amd.scheduler import DDIMScheduler
 
+    BF16 = torch.bfloat16
     tcfg = dict(iw.TRANSFORMER_5B, num_layers=args.layers)
     with torch.device("meta"):
         tr = CrossTransformer3DModel(**tcfg)
@@ -67,25 +109,27 @@ def build_models(args, device):
                                device=device)
     vae.load_state_dict(vsd, strict=True, assign=True)
     tr.eval(), vae.eval()
-    return TrajCrafter_Pipeline(None, None, vae, tr, DDIMScheduler()), tcfg
+    return TrajCrafter_Pipeline(None, None, vae, tr, DDIMScheduler())
 
 
 def make_inputs(args, device, seed):
+    import torch
     g = torch.Generator(device=device).manual_seed(seed)
     T = (args.frames - 1) // 4 + 1
     h, w = args.height // 8, args.width // 8
-    rn = lambda *s: torch.randn(*s, device=device, dtype=BF16, generator=g)
+    rn = lambda *s: torch.randn(*s, device=device, dtype=torch.bfloat16, generator=g)
     return dict(latents=rn(1, T, 16, h, w), prompt_embeds=rn(1, 226, 4096), negative_prompt_embeds=rn(1, 226, 4096),
                 inpaint_latents=rn(2, T, 17, h, w), ref_latents=rn(2, 3, 16, h, w))
 
 
-def cpu_baseline(args, threads: int = 16, attn_heads: int = 4, cross_heads: int = 2):
-    """Oracle (CPU port of the reference, fp32) on the host cores, bounded to ~10-30 s: at the full
-    480x720 token count, B=1, time (a) every row-wise / GEMM piece of ONE CogVideoXBlock, (b) its joint
-    attention on `attn_heads` of the 48 heads, (c) the GEMMs + LayerNorms of ONE PerceiverCrossAttention and
-    (d) its attention on `cross_heads` of the 16 heads; heads are independent, so (b) and (d) scale linearly.
-    A clip is extrapolated as 2*steps forwards x (42 blocks + 21 cross layers).  Reported baseline, not the target."""
-    import torch.nn.functional as F
+# ------------------------------------------------------------------------------------------- CPU baseline (oracle)
+def cpu_baseline(args, threads: int = 16, attn_heads: int = 2, cross_heads: int = 1):
+    """Oracle (CPU port of the reference, fp32) on the host cores, bounded to ~10-20 s: at the full 480x720 token count,
+    B=1, time (a) every row-wise / GEMM piece of ONE CogVideoXBlock, (b) its joint attention on `attn_heads` of the 48
+    heads, (c) the GEMMs + LayerNorms of ONE PerceiverCrossAttention and (d) its attention on `cross_heads` of the 16
+    heads; heads are independent, so (b) and (d) scale linearly.  A clip is extrapolated as 2*steps forwards x (42 blocks +
+    21 cross layers).  Reported baseline, not the target."""
+    import torch
     from oracle import diffusers_restated as dr
     from oracle import transformer as otr
     from oracle.pipeline import prepare_rotary
@@ -95,7 +139,9 @@ def cpu_baseline(args, threads: int = 16, attn_heads: int = 4, cross_heads: int 
     threads = max(1, min(threads, os.cpu_count() or 1))        # the box's CPU share for one GPU is 16 cores
     torch.set_num_threads(threads)
     cfg = dict(otr.DEFAULT_CONFIG, **dict(iw.TRANSFORMER_5B, num_layers=2))
-    sd = iw.random_state_dict(iw.transformer_param_shapes(cfg), seed=0)
+    shapes = {k: v for k, v in iw.transformer_param_shapes(cfg).items()
+              if k.startswith(("transformer_blocks.0.", "perceiver_cross_attention.0."))}
+    sd = iw.random_state_dict(shapes, seed=0)
     T = (args.frames - 1) // 4 + 1
     gh, gw = args.height // 16, args.width // 16
     Sv, S, Sr, D = T * gh * gw, T * gh * gw + 226, 3 * gh * gw, 3072
@@ -150,12 +196,55 @@ def cpu_baseline(args, threads: int = 16, attn_heads: int = 4, cross_heads: int 
             "extrapolated_clip_seconds": clip_s}
 
 
-def main():
-    args = parse()
+def cpu_baseline_bounded(args):
+    """Run `cpu_baseline` on a worker thread; after CPU_BASELINE_BUDGET_S give up so that the JSON line is always printed."""
+    import concurrent.futures as cf
+    ex = cf.ThreadPoolExecutor(max_workers=1)
+    fut = ex.submit(cpu_baseline, args)
+    try:
+        return fut.result(timeout=CPU_BASELINE_BUDGET_S), False
+    except cf.TimeoutError:
+        return {"value": None, "unit": "video-latents/s", "cores": None, "kind": "port",
+                "sample": f"skipped: the oracle sample did not finish within {CPU_BASELINE_BUDGET_S:.0f} s on this host"}, True
+    except Exception as e:                                       # the baseline is a reported extra: never lose the bench line
+        return {"value": None, "unit": "video-latents/s", "cores": None, "kind": "port", "sample": f"skipped: {type(e).__name__}: {e}"}, False
+
+
+# ------------------------------------------------------------------------------------------- rank plumbing
+def _selftest_rank(args, rank, world):
+    """CPU-only rehearsal of the N-rank control flow on gloo (tests/test_bench_launcher.py): rendezvous, barrier, max-reduce
+    of the elapsed time, the single all-gather, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    from trajectorycrafter_amd import dp
+    if world > 1:
+        dp.init_distributed("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    local = torch.full((1, 3, 2, 4, 4), float(43 + rank))
+    elapsed = torch.tensor([time.perf_counter() - t0 + 1e-3 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    frames = dp.all_gather_cat(local)
+    assert frames.shape[0] == world and frames[:, 0, 0, 0, 0].tolist() == [float(43 + r) for r in range(world)]
+    if rank == 0:
+        print(json.dumps({"metric": "selftest", "value": world / float(elapsed), "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "gathered": list(frames.shape)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_rank(args):
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        print(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}", file=sys.stderr, flush=True)
+    if args.selftest_dist:
+        return _selftest_rank(args, rank, world)
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # rehearsal knobs (never set by the driver): run several ranks on ONE GPU with gloo to exercise the N > 1 control flow
+    # rehearsal knob (never set by the driver): several ranks on ONE GPU with gloo to exercise the N > 1 control flow
     if os.environ.get("TCX_BENCH_SINGLE_DEVICE") == "1":
         local = 0
     torch.cuda.set_device(local)
@@ -165,14 +254,15 @@ def main():
 
     if world > 1:
         dp.init_distributed(os.environ.get("TCX_DIST_BACKEND", "nccl"))
-    pipe, tcfg = build_models(args, device)
+    t_init = time.perf_counter()
+    pipe = build_models(args, device)
+    if args.graph is not None:
+        pipe.transformer.use_hip_graph = bool(args.graph)
     inp = make_inputs(args, device, seed=43 + rank)            # one independent trajectory per rank (seeds 43..50)
-
-    def one_clip():
-        out = pipe(prompt=None, height=args.height, width=args.width, num_frames=args.frames,
-                   num_inference_steps=args.denoise_steps, guidance_scale=6.0,
-                   output_type="latent" if args.no_decode else "pt", **inp).videos
-        return dp.all_gather_cat(out) if world > 1 else out     # the single RCCL all-gather of the path
+    st = pipe.prepare_denoise(prompt=None, height=args.height, width=args.width, num_frames=args.frames,
+                              num_inference_steps=args.denoise_steps, guidance_scale=6.0, **inp)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t_init
 
     def barrier():
         torch.cuda.synchronize()
@@ -180,23 +270,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, reps=1):
+        """fn() `reps` times between barrier + synchronize pairs -> seconds, max over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    it = {"i": 0}
+
+    def one_step():                                             # consecutive steps of one trajectory; wraps after a clip
+        t = st.timesteps[it["i"] % len(st.timesteps)]
+        it["i"] += 1
+        return pipe.denoise_step(st, t)
+
     for _ in range(args.warmup):
-        one_clip()
+        one_step()
     ops.attn_timing_start()                                     # HIP events around every tcx_attn_fwd launch
-    barrier()
-    t0 = time.perf_counter()
-    denoise_s = decode_s = 0.0
-    for _ in range(args.steps):
-        out = one_clip()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tm = pipe.timings()
+    elapsed, _ = timed(one_step, args.steps)
     attn = ops.attn_timing_stop()
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert out.shape[0] == world and torch.isfinite(out.float()).all()
+    step_s = elapsed / args.steps
+    lat = st.latents
+    assert torch.isfinite(lat.float()).all(), "non-finite latents after the timed steps"
+
+    decode_s = gather_s = 0.0
+    frames_shape = None
+    if not args.no_decode:
+        if world == 1:
+            pipe.decode_latents(lat)                            # warm-up decode (allocator, weight permutes)
+            decode_s, frames = timed(lambda: pipe.decode_latents(lat))       # product call: fp32 frames [1,3,49,H,W] in [0,1]
+        else:
+            # each rank decodes its own clip to the decoder's bf16 output (channels-last, 102 MB), ONE all-gather moves
+            # that, and the fp32 frame conversion (pipeline decode_latents :514-517) runs on the gathered tensor: bit-identical
+            # to decode_latents per clip at half the bytes of gathering fp32 frames
+            dec = lambda: pipe.vae.decode_cl_bf16(lat.permute(0, 2, 1, 3, 4), scale=1.0 / pipe.vae.config.scaling_factor)
+            dec()
+            decode_s, out_cl = timed(dec)
+            gat = lambda: pipe.vae.cl_to_frames(dp.all_gather_cat(out_cl))
+            gat()                                               # warm-up (RCCL channel set-up)
+            gather_s, frames = timed(gat)                       # THE collective of the path: once per clip
+        assert frames.shape[0] == world and torch.isfinite(frames).all() and 0.0 <= float(frames.min()) and float(frames.max()) <= 1.0
+        frames_shape = list(frames.shape)
 
     if rank == 0:
         S = ((args.frames - 1) // 4 + 1) * (args.height // 16) * (args.width // 16) + 226
@@ -205,38 +326,59 @@ def main():
         avg_ms = sa["ms"] / max(sa["n"], 1)
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         fwd_flop = {(49, 480, 720): 3.5585e14, (49, 384, 672): 2.3387e14}.get((args.frames, args.height, args.width))
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r1_attn_pmc.json")        # PMC counters cannot be read inside the timed run:
-        if os.path.exists(pmc) and (args.frames, args.height, args.width) == (49, 480, 720):   # committed rocprofv3 --pmc result
-            with open(pmc) as f:
-                traffic = json.load(f).get("traffic_bytes_per_launch")
+        traffic, traffic_src = None, None
+        for name in ("r2_attn_pmc.json", "r1_attn_pmc.json"):   # PMC counters cannot be read inside the timed run: committed
+            pmc = os.path.join(ROOT, "profiles", name)          # rocprofv3 --pmc result of the same kernel and shape
+            if os.path.exists(pmc) and (args.frames, args.height, args.width) == (49, 480, 720):
+                with open(pmc) as f:
+                    traffic = json.load(f).get("traffic_bytes_per_launch")
+                traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+                break
         benchmark_config = (args.denoise_steps, args.height, args.width, args.frames, args.layers, args.no_decode) == (50, 480, 720, 49, 42, False)
+        clip_s = args.denoise_steps * step_s + decode_s + gather_s
         rec = {
-            "metric": "denoised video-latents/sec (49f, 480x720)", "value": world * args.steps / elapsed,
+            "metric": "denoised video-latents/sec (49f, 480x720)", "value": world / clip_s,
             "unit": "video-latents/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * step_s, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("configs[2]: full 50-step DDIM (CFG 6, B=2 per step) + VAE decode, 49f 480x720, random-init 42-layer "
                                     "CrossTransformer3D (the 6.1 B-param 5B model); one independent trajectory per GPU") if benchmark_config else
                                    (f"DEBUG (not the benchmark config): {args.denoise_steps}-step DDIM, {args.frames}f {args.height}x{args.width}, "
                                     f"{args.layers} layers, decode={not args.no_decode}"),
+                       "step": "one CFG denoising step at full size: B=2 forward of the 42-block model + fused CFG/DDIM update "
+                               "(TrajCrafter_Pipeline.denoise_step = reference pipeline_trajectorycrafter.py:1093-1178)",
+                       "value_formula": "n_gpus / (denoise_steps * ms_per_step + decode_ms + allgather_ms) * 1000",
                        "frames": args.frames, "height": args.height, "width": args.width, "denoise_steps": args.denoise_steps,
                        "layers": args.layers, "vae_decode": not args.no_decode, "global_batch_clips": world,
-                       "parallelism": f"dp{world}", "last_clip_denoise_s": tm["denoise_s"], "last_clip_decode_s": tm["decode_s"],
+                       "parallelism": f"dp{world}", "decode_ms": 1e3 * decode_s, "allgather_ms": 1e3 * gather_s,
+                       "clip_seconds": clip_s, "timed_steps_seconds": elapsed, "init_seconds": t_init,
+                       "hip_graph": bool(getattr(pipe.transformer, "use_hip_graph", False)), "frames_out": frames_shape,
                        "transformer_mfma_frac": (None if fwd_flop is None else
-                                                 2 * args.denoise_steps * fwd_flop * (args.layers / 42) / tm["denoise_s"] / 1e12 / PEAK_BF16_TFLOPS)},
+                                                 2 * fwd_flop * (args.layers / 42) / step_s / 1e12 / PEAK_BF16_TFLOPS)},
             "roofline": {"kernel": "tcx_attn_fwd<64> (joint self-attention, 42 launches per step)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                         "traffic": traffic, "traffic_source": "profiles/r1_attn_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "launches": sa["n"], "avg_launch_ms": avg_ms,
                          "algorithmic_flop_per_launch": flop_per_launch},
         }
+        hung = False
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(args)
+            rec["cpu_baseline"], hung = cpu_baseline_bounded(args)
         print(json.dumps(rec), flush=True)
+        if hung:                                                # the oracle thread is still running: leave without joining it
+            sys.stdout.flush()
+            os._exit(0)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, argv))                     # no torch.cuda / HIP call has happened in this process
+    run_rank(args)
 
 
 if __name__ == "__main__":

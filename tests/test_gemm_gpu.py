@@ -52,7 +52,10 @@ def _check(got, want, scale=1.0):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 256), (1, 256, 128), (777, 768, 384), (452, 3072, 4096),
-                                   (300, 128, 128), (64, 384, 512), (100, 520, 128), (2, 64, 3072)])
+                                   (300, 128, 128), (64, 384, 512), (100, 520, 128), (2, 64, 3072),
+                                   # K-tail instantiation (K % 128 != 0: zero-filled last K-tile, odd tile counts)
+                                   (300, 256, 32), (513, 264, 200), (260, 512, 136), (97, 64, 8), (300, 128, 192),
+                                   (2, 192, 64), (700, 520, 328)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_matches_oracle(ops, M, N, K, epi):
     g = torch.Generator().manual_seed(M * 7 + N + K + epi)
@@ -106,10 +109,25 @@ def test_gemm_rejects_bad_shapes(ops):
     with pytest.raises(TcxError):
         ops.gemm_bf16(x, torch.zeros(60, 128, dtype=BF, device="cuda"))           # N % 8
     with pytest.raises(TcxError):
-        ops.gemm_bf16(x[:, :64], torch.zeros(256, 64, dtype=BF, device="cuda"))     # K % 128
+        ops.gemm_bf16(x[:, :60], torch.zeros(256, 60, dtype=BF, device="cuda"))     # K % 8
     with pytest.raises(TcxError):
         ops.gemm_bf16(x, torch.zeros(256, 128, dtype=BF, device="cuda"), epilogue=2)   # no res
-    assert ops.gemm_supported(3072, 12288) and ops.gemm_supported(64, 3072) and not ops.gemm_supported(3072, 132)
+    assert ops.gemm_supported(3072, 12288) and ops.gemm_supported(64, 3072) and ops.gemm_supported(256, 32)
+    assert not ops.gemm_supported(3072, 132)          # rows of W would not be 16-byte aligned: callers pad K (patch embed)
+
+
+def test_gemm_k_tail_ignores_what_lies_beyond_k(ops):
+    """K-tail: the k-slots at or beyond K come from a page of zeros, not from memory — x a column slice [:, :K] of a wider
+    buffer whose remaining columns hold NaN / huge values, and W rows followed directly by the next row."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K, Kw = 130, 72, 40, 128
+    wide = torch.full((M, Kw), float("nan")).to(BF)
+    wide[:, :K] = torch.randn(M, K, generator=g).to(BF)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    b = torch.randn(N, generator=g).to(BF)
+    got = ops.gemm_bf16(wide.cuda()[:, :K], w.cuda(), b.cuda())
+    assert bool(torch.isfinite(got.float()).all())
+    _check(got, _oracle(wide[:, :K], w, b, 0), scale=2.0)
 
 
 def test_gemm_full_size_repeatable_and_linear(ops):

@@ -671,12 +671,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 template <int D, bool F32, bool FAST, int NW, bool BOUND>
 int launch_one(AttnParams p, hipStream_t st) {
     constexpr int lds = 2 * (D == 64 ? 4 : 2) * 64 * D * 2;   // K ring + V ring, R slots each
-    static bool attr_done = false;  // idempotent; racing threads set the same value
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, F32, FAST, NW, BOUND>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+    static TcxPerDeviceOnce lds_attr;   // per (kernel instantiation, device)
+    const int arc = tcx_ensure_dynamic_lds(lds_attr, reinterpret_cast<const void*>(&attn_fwd_kernel<D, F32, FAST, NW, BOUND>), lds, "tcx_attn_fwd");
+    if (arc != TCX_OK) return arc;
     p.nqb = (uint32_t)((p.Sq + 32 * NW - 1) / (32 * NW));
     p.nwg = p.nqb * (uint32_t)(p.B * p.H);
     hipLaunchKernelGGL((attn_fwd_kernel<D, F32, FAST, NW, BOUND>), dim3(p.nwg), dim3(64 * NW), lds, st, p);

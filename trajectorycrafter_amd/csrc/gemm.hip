@@ -33,7 +33,10 @@
 //  * XCD-aware, bijective block remap; within an XCD's chunk tiles are ordered 4 (M) x all (N) so the 32 workgroups
 //    sharing an L2 reuse each X tile 8x and each W tile 4x.
 //  * Rows >= M / columns >= N are loaded from the last valid row of X / W and masked at the store; N % 8 == 0 and
-//    K % 128 == 0 are required (every Linear of the 5B transformer except the K = 132 patch embedding).
+//    K % 8 == 0 are required.  K % 128 == 0 (every Linear of the 5B transformer) runs the plain loop; any other K runs the
+//    KTAIL instantiation: the K range is rounded up to an even number of 64-deep K-tiles and every 16-byte k-slot at or
+//    beyond K is fetched from a 16-byte page of zeros in the code object instead (LDS-DMA takes a per-lane source
+//    address, so "zero-fill" is just another address; two compares and selects per staged piece).
 #include "tcx_common.h"
 #include <type_traits>
 
@@ -70,7 +73,10 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 
 #define TCX_SB() __builtin_amdgcn_sched_barrier(0)
 
-template <int EPI>
+// what a k-slot at or beyond K reads (KTAIL): zeros contribute nothing to the accumulators
+__device__ __attribute__((aligned(16))) const uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+template <int EPI, bool KTAIL>
 __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -84,15 +90,17 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
     const int tm = band * GM + rr % gme, tn = rr / gme;
     const int64_t m0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
-    const int KT = p.K / BK;
+    const int KT = KTAIL ? ((p.K + 2 * BK - 1) / (2 * BK)) * 2 : p.K / BK;     // even number of K-tiles
 
     // ---- staging addresses: wave `wid` writes the 1-KiB pieces 2*wid, 2*wid+1 of every half-tile ----
     const uint16_t* px[2][2];
     const uint16_t* pw[2][2];
+    int kofs[2];                                                        // KTAIL: first k of the lane's slot inside a K-tile
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int lr = (wid * 2 + j) * 8 + (lane >> 3);                 // row of the half-tile
         const int ksl = (lane & 7) ^ ((lr >> 1) & 7);                   // source k-slot of LDS slot (lane & 7)
+        kofs[j] = ksl * 8;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             int64_t row = m0 + (lr >> 6) * 128 + q * 64 + (lr & 63);
@@ -111,6 +119,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const uint16_t* src = (H < 2 ? px[H & 1][j] : pw[H & 1][j]) + (int64_t)kt * BK;
+            if constexpr (KTAIL) {
+                if (kt * BK + kofs[j] >= p.K) src = reinterpret_cast<const uint16_t*>(g_zero_page);
+            }
             char* dst = lds + buf * BUF + H * HALF + (wid * 2 + j) * 1024;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
         }
@@ -384,16 +395,18 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
     else store_rows(std::false_type{});
 }
 
+template <int EPI, bool KTAIL>
+int launch_gemm_k(const GemmParams& p, hipStream_t st) {
+    static TcxPerDeviceOnce lds_attr;          // hipFuncSetAttribute is per device: once per (kernel, device), thread-safe
+    const int rc = tcx_ensure_dynamic_lds(lds_attr, reinterpret_cast<const void*>(&gemm_kernel<EPI, KTAIL>), LDS_BYTES, "tcx_gemm_bf16");
+    if (rc != TCX_OK) return rc;
+    hipLaunchKernelGGL((gemm_kernel<EPI, KTAIL>), dim3((unsigned)(p.mt * p.nt)), dim3(512), LDS_BYTES, st, p);
+    TCX_LAUNCH_RET();
+}
+
 template <int EPI>
 int launch_gemm(const GemmParams& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) { tcx_set_error("tcx_gemm_bf16: cannot reserve %d bytes of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm_kernel<EPI>, dim3((unsigned)(p.mt * p.nt)), dim3(512), LDS_BYTES, st, p);
-    TCX_LAUNCH_RET();
+    return p.K % (2 * BK) == 0 ? launch_gemm_k<EPI, false>(p, st) : launch_gemm_k<EPI, true>(p, st);
 }
 
 }  // namespace
@@ -405,7 +418,7 @@ extern "C" int tcx_gemm_bf16(const void* x, const void* w, const void* bias, voi
     TCX_CHECK(x && w && y, TCX_E_NULL, "tcx_gemm_bf16: null x / w / y");
     TCX_CHECK(M < (1ll << 31), TCX_E_SHAPE, "tcx_gemm_bf16: M=%lld exceeds 2^31 rows", (long long)M);
     TCX_CHECK(M > 0 && N > 0 && K > 0, TCX_E_SHAPE, "tcx_gemm_bf16: empty shape M=%lld N=%d K=%d", (long long)M, N, K);
-    TCX_CHECK(N % 8 == 0 && K % (2 * BK) == 0, TCX_E_SHAPE, "tcx_gemm_bf16: needs N %% 8 == 0 and K %% 128 == 0 (N=%d K=%d)", N, K);
+    TCX_CHECK(N % 8 == 0 && K % 8 == 0, TCX_E_SHAPE, "tcx_gemm_bf16: needs N %% 8 == 0 and K %% 8 == 0 (N=%d K=%d)", N, K);
     TCX_CHECK(ldx >= K && ldy >= N && ldx % 8 == 0 && ldy % 8 == 0, TCX_E_SHAPE, "tcx_gemm_bf16: bad leading dimensions ldx=%lld ldy=%lld", (long long)ldx, (long long)ldy);
     TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(w) && tcx_aligned16(y) && tcx_aligned16(bias), TCX_E_ALIGN, "tcx_gemm_bf16: pointers must be 16-byte aligned");
     TCX_CHECK(epilogue >= 0 && epilogue <= 2, TCX_E_SHAPE, "tcx_gemm_bf16: unknown epilogue %d", epilogue);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/tcx_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -36,6 +37,27 @@ void tcx_set_error(const char* fmt, ...);
     } while (0)
 
 static inline bool tcx_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE property of a kernel: a process that drives several GPUs must
+// set it on each of them.  One of these per kernel instantiation: a bit per device ordinal (ordinals >= 64 simply set the
+// attribute on every launch), written with an atomic OR so that racing host threads at worst set the attribute twice.
+struct TcxPerDeviceOnce {
+    std::atomic<uint64_t> done{0};
+};
+static inline int tcx_ensure_dynamic_lds(TcxPerDeviceOnce& once, const void* func, int bytes, const char* what) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { tcx_set_error("%s: hipGetDevice: %s", what, hipGetErrorString(e)); return (int)e; }
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked && ((once.done.load(std::memory_order_acquire) >> dev) & 1ull)) return TCX_OK;
+    e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        tcx_set_error("%s: cannot reserve %d bytes of LDS on device %d: %s", what, bytes, dev, hipGetErrorString(e));
+        return (int)e;
+    }
+    if (tracked) once.done.fetch_or(1ull << dev, std::memory_order_release);
+    return TCX_OK;
+}
 
 // ---- device helpers ----
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }

@@ -496,6 +496,20 @@ class AutoencoderKLCogVideoX(ModelMixin, ConfigMixin):
         return frames
 
     @torch.no_grad()
+    def decode_cl_bf16(self, z: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+        """decode -> the decoder's own bf16 output, channels-last [N,T',H,W,3]: what the data-parallel runner all-gathers
+        (half the bytes of the fp32 frames and lossless: `cl_to_frames` of it is bit-identical to `decode_to_frames`)."""
+        return torch.cat(self._decode_cl(z, None, scale), dim=1)
+
+    @torch.no_grad()
+    def cl_to_frames(self, x_cl: torch.Tensor) -> torch.Tensor:
+        """channels-last bf16 decoder output [N,T,H,W,C] -> fp32 frames [N,C,T,H,W] = (x/2+.5).clamp(0,1) (:514-517)."""
+        N, T, H, W, C = x_cl.shape
+        frames = torch.empty((N, C, T, H, W), device=x_cl.device, dtype=torch.float32)
+        ops.cl_to_frames(x_cl.contiguous(), frames, 0)
+        return frames
+
+    @torch.no_grad()
     def encode(self, x: torch.Tensor, return_dict: bool = True):
         """reference :1176-1215: x [N,3,F,H,W] bf16 in [-1,1] -> posterior over [N,16,T,H/8,W/8] (4-frame chunks
         with the remainder folded into the first, conv caches carried across chunks)."""

@@ -45,20 +45,11 @@ def _linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, 
             res: Optional[torch.Tensor] = None, gate_v: Optional[torch.Tensor] = None,
             gate_t: Optional[torch.Tensor] = None, text_len: int = 0) -> torch.Tensor:
     """y = epilogue(x @ w.T + b), bf16 in / fp32 accumulate / bf16 out, on the hand-written MFMA kernel
-    (`tcx_gemm_bf16`) for every shape it takes (N % 8 == 0, K % 128 == 0: all Linears of the blocks, embeddings and
-    modulations of the 5B model).  GEMM_GATED_RESIDUAL updates `res` in place and returns it.
-    Other shapes (K % 128 != 0: narrow test configurations only — the patch embeddings are zero-padded to K = 256 / 128)
-    are a plain library GEMM followed by the stand-alone HIP epilogue kernels."""
-    if ops.gemm_supported(w.shape[0], w.shape[1]):
-        if epilogue == ops.GEMM_GATED_RESIDUAL:
-            return ops.gemm_bf16(x, w, b, epilogue=epilogue, res=res, gate_v=gate_v, gate_t=gate_t, text_len=text_len, out=res)
-        return ops.gemm_bf16(x, w, b, epilogue=epilogue)
-    if epilogue == ops.GEMM_BIAS_GELU:
-        return ops.bias_gelu_tanh_(F.linear(x, w), b)
-    y = F.linear(x, w, b)
+    (`tcx_gemm_bf16`): every Linear of every configuration (N % 8 == 0, K % 8 == 0; K % 128 != 0 takes the kernel's
+    zero-filled K-tail).  GEMM_GATED_RESIDUAL updates `res` in place and returns it.  There is no library-GEMM path."""
     if epilogue == ops.GEMM_GATED_RESIDUAL:
-        return ops.gated_residual_(res, y.view(res.shape), gate_v, gate_t, text_len)
-    return y
+        return ops.gemm_bf16(x, w, b, epilogue=epilogue, res=res, gate_v=gate_v, gate_t=gate_t, text_len=text_len, out=res)
+    return ops.gemm_bf16(x, w, b, epilogue=epilogue)
 
 
 def _conv_as_gemm_weight(conv: nn.Conv2d, cache: dict) -> torch.Tensor:

@@ -78,10 +78,38 @@ def resize_mask(mask, latent, process_first_frame_only=True):
     return F.interpolate(mask, size=list(latent_size[2:]), mode="trilinear", align_corners=False)
 
 
+def add_noise_to_reference_video(image: torch.Tensor, ratio: Optional[float] = None) -> torch.Tensor:
+    """reference :163-175: per-sample Gaussian pixel noise (sigma = `ratio`, or exp(N(-3, 0.5)) when None), none on the
+    masked-out pixels (== -1); drawn from the global RNG in `image`'s dtype on `image`'s device, as the reference does."""
+    if ratio is None:
+        sigma = torch.exp(torch.normal(mean=-3.0, std=0.5, size=(image.shape[0],)).to(image.device)).to(image.dtype)
+    else:
+        sigma = torch.ones((image.shape[0],)).to(image.device, image.dtype) * ratio
+    noise = torch.randn_like(image) * sigma[:, None, None, None, None]
+    noise = torch.where(image == -1, torch.zeros_like(image), noise)
+    return image + noise
+
+
 @dataclass
 class CogVideoX_Fun_PipelineOutput:
     """reference :178-190."""
     videos: torch.Tensor
+
+
+@dataclass
+class DenoiseState:
+    """What the reference's loop (:1089-1198) carries from iteration to iteration, plus its constant inputs."""
+    latents: torch.Tensor                    # [B,T,16,h,w] bf16
+    prompt_embeds: torch.Tensor              # [2B,226,4096] (negative first) when do_cfg
+    inpaint_latents: torch.Tensor            # [2B,T,17,h,w]
+    ref_input: torch.Tensor                  # [2B,Tr,16,h,w]
+    image_rotary_emb: Optional[Tuple[torch.Tensor, torch.Tensor]]
+    timesteps: List[int]
+    num_inference_steps: int
+    batch_size: int
+    do_cfg: bool
+    guidance_scale: float
+    use_dynamic_cfg: bool = False
 
 
 class TrajCrafter_Pipeline:
@@ -251,7 +279,8 @@ class TrajCrafter_Pipeline:
             y = (y >= 0.5).to(y.dtype)
         return y.reshape(b, f, c, height, width).permute(0, 2, 1, 3, 4)
 
-    def _build_conditioning(self, video, mask_video, reference, height, width, do_cfg, dtype, device):
+    def _build_conditioning(self, video, mask_video, reference, height, width, do_cfg, dtype, device,
+                            noise_aug_strength: Optional[float] = 0.0563):
         """reference :862-897 and :927-1028: pixels -> (inpaint_latents [B,T,17,h,w], ref_latents [B,Tr,16,h,w]) through
         the HIP VAE encoder.  The elementwise preparation (normalise, binarise, trilinear mask resize) is
         conditioning I/O on small tensors and stays in torch."""
@@ -273,6 +302,8 @@ class TrajCrafter_Pipeline:
             mask_cond = self._preprocess(mask_video.to(device), height, width, do_normalize=False, do_binarize=True)
             tile = mask_cond.repeat(1, 3, 1, 1, 1)
             masked_video = init_video * (tile < 0.5) + torch.ones_like(init_video) * (tile > 0.5) * -1   # :969-974
+            if self.transformer.config.add_noise_in_inpaint_model:                                     # :488-491
+                masked_video = add_noise_to_reference_video(masked_video, ratio=noise_aug_strength)
             mv = (self.vae.encode(masked_video.to(dtype))[0].mode() * sf).to(dtype)                    # :498-502
             mask_lat = (resize_mask(1 - mask_cond, mv) * sf).to(dtype).permute(0, 2, 1, 3, 4)          # :991-996
             mv_lat = mv.permute(0, 2, 1, 3, 4)
@@ -312,13 +343,58 @@ class TrajCrafter_Pipeline:
         inpaint_latents: Optional[torch.Tensor] = None,
         ref_latents: Optional[torch.Tensor] = None,
     ) -> CogVideoX_Fun_PipelineOutput:
+        st = self.prepare_denoise(
+            prompt=prompt, negative_prompt=negative_prompt, height=height, width=width, video=video, mask_video=mask_video,
+            reference=reference, num_frames=num_frames, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+            use_dynamic_cfg=use_dynamic_cfg, eta=eta, generator=generator, latents=latents, prompt_embeds=prompt_embeds,
+            negative_prompt_embeds=negative_prompt_embeds, callback_on_step_end_tensor_inputs=callback_on_step_end_tensor_inputs,
+            max_sequence_length=max_sequence_length, strength=strength, noise_aug_strength=noise_aug_strength,
+            inpaint_latents=inpaint_latents, ref_latents=ref_latents)
+
+        # 8. denoising loop (:1089-1198)
+        ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        ev0.record()
+        for i, t in enumerate(st.timesteps):
+            if self.interrupt:
+                continue
+            self.denoise_step(st, t)
+            if callback_on_step_end is not None:                                       # :1181-1190
+                latents, prompt_embeds = st.latents, st.prompt_embeds
+                negative_prompt_embeds = st.prompt_embeds[:st.batch_size] if st.do_cfg else None
+                callback_kwargs = {k: locals()[k] for k in callback_on_step_end_tensor_inputs}
+                callback_outputs = callback_on_step_end(self, i, t, callback_kwargs)
+                st.latents = callback_outputs.pop("latents", st.latents)
+                st.prompt_embeds = callback_outputs.pop("prompt_embeds", st.prompt_embeds)
+        ev1.record()
+
+        if output_type == "latent":
+            video_out = st.latents
+        else:
+            video_out = self.decode_latents(st.latents)
+        ev2.record()
+        if output_type in ("numpy", "np"):
+            video_out = video_out.cpu()                 # reference :517 / :1214 returns a CPU float tensor
+        self._events = (ev0, ev1, ev2)
+        self.maybe_free_model_hooks()
+        return CogVideoX_Fun_PipelineOutput(videos=video_out)
+
+    # ---- the loop body and its set-up as separate entry points: `__call__` above is prepare -> N x step -> decode; bench.py
+    #      times `denoise_step` itself, so the measured step IS the product step ----
+    @torch.no_grad()
+    def prepare_denoise(self, prompt=None, negative_prompt=None, height=480, width=720, video=None, mask_video=None,
+                        reference=None, num_frames=49, num_inference_steps=50, guidance_scale=6, use_dynamic_cfg=False,
+                        eta=0.0, generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None,
+                        callback_on_step_end_tensor_inputs=("latents",), max_sequence_length=226, strength=1,
+                        noise_aug_strength=0.0563, inpaint_latents=None, ref_latents=None) -> "DenoiseState":
+        """Everything of reference `__call__` before the loop (:786-1087): checks, prompt embeddings, timesteps,
+        conditioning latents, initial noise, rotary tables."""
         if num_frames > 49:
             raise ValueError("The number of frames must be less than 49 for now due to static positional embeddings. "
                              "This will be updated in the future to remove this limitation.")
         if eta != 0.0 or strength != 1:
             raise ValueError("only eta = 0 and strength = 1 (the reference's inference settings) are implemented")
         num_videos_per_prompt = 1
-        self.check_inputs(prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs, prompt_embeds,
+        self.check_inputs(prompt, height, width, negative_prompt, list(callback_on_step_end_tensor_inputs), prompt_embeds,
                           negative_prompt_embeds)
         self._guidance_scale = guidance_scale
         self._interrupt = False
@@ -350,7 +426,7 @@ class TrajCrafter_Pipeline:
         # 5. conditioning + latents (:862-1068)
         if inpaint_latents is None or ref_latents is None:
             inpaint_latents, ref_latents = self._build_conditioning(video, mask_video, reference, height, width, do_cfg,
-                                                                    BF16, device)
+                                                                    BF16, device, noise_aug_strength)
         video_length = video.shape[2] if video is not None else num_frames           # quirk: real count = video.shape[2]
         rep = 2 if do_cfg else 1
         inpaint_latents = inpaint_latents.to(device=device, dtype=BF16)
@@ -369,44 +445,32 @@ class TrajCrafter_Pipeline:
         # 7. rotary tables (:1076-1082)
         image_rotary_emb = (self._prepare_rotary_positional_embeddings(height, width, latents.size(1), device)
                             if self.transformer.config.use_rotary_positional_embeddings else None)
+        return DenoiseState(latents=latents, prompt_embeds=prompt_embeds, inpaint_latents=inpaint_latents.contiguous(),
+                            ref_input=ref_input.contiguous(), image_rotary_emb=image_rotary_emb,
+                            timesteps=[int(t) for t in timesteps.tolist()], num_inference_steps=num_inference_steps,
+                            batch_size=batch_size, do_cfg=do_cfg, guidance_scale=float(guidance_scale),
+                            use_dynamic_cfg=use_dynamic_cfg)
 
-        # 8. denoising loop (:1089-1198)
-        ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        ev0.record()
-        for i, t in enumerate(timesteps.tolist()):
-            if self.interrupt:
-                continue
-            latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
-            timestep = torch.full((latent_model_input.shape[0],), t, device=device, dtype=torch.int64)
-            noise_pred = self.transformer(hidden_states=latent_model_input, encoder_hidden_states=prompt_embeds,
-                                          timestep=timestep, image_rotary_emb=image_rotary_emb, return_dict=False,
-                                          inpaint_latents=inpaint_latents, cross_latents=ref_input)[0]
-            if use_dynamic_cfg:                                                        # :1142-1156
-                self._guidance_scale = 1 + guidance_scale * (
-                    (1 - math.cos(math.pi * ((num_inference_steps - t) / num_inference_steps) ** 5.0)) / 2)
-            a_t, a_prev = self.scheduler.coeffs(t)
-            if do_cfg:                                                                 # :1157-1178 fused
-                u, c = noise_pred[:batch_size], noise_pred[batch_size:]
-                latents = ops.cfg_ddim_step(u, c, latents, self.guidance_scale, a_t, a_prev)
-            else:
-                latents = ops.cfg_ddim_step(noise_pred, None, latents, 1.0, a_t, a_prev)
-            if callback_on_step_end is not None:                                       # :1181-1190
-                callback_kwargs = {k: locals()[k] for k in callback_on_step_end_tensor_inputs}
-                callback_outputs = callback_on_step_end(self, i, t, callback_kwargs)
-                latents = callback_outputs.pop("latents", latents)
-                prompt_embeds = callback_outputs.pop("prompt_embeds", prompt_embeds)
-        ev1.record()
-
-        if output_type == "latent":
-            video_out = latents
+    @torch.no_grad()
+    def denoise_step(self, st: "DenoiseState", t: int) -> torch.Tensor:
+        """One iteration of the reference loop (:1093-1178): CFG-batched transformer forward, guidance, DDIM update,
+        bf16 latents.  Updates and returns `st.latents`.  No host synchronisation."""
+        device = st.latents.device
+        latent_model_input = torch.cat([st.latents] * 2) if st.do_cfg else st.latents
+        timestep = torch.full((latent_model_input.shape[0],), t, device=device, dtype=torch.int64)
+        noise_pred = self.transformer(hidden_states=latent_model_input, encoder_hidden_states=st.prompt_embeds,
+                                      timestep=timestep, image_rotary_emb=st.image_rotary_emb, return_dict=False,
+                                      inpaint_latents=st.inpaint_latents, cross_latents=st.ref_input)[0]
+        if st.use_dynamic_cfg:                                                     # :1142-1156
+            n = st.num_inference_steps
+            self._guidance_scale = 1 + st.guidance_scale * ((1 - math.cos(math.pi * ((n - t) / n) ** 5.0)) / 2)
+        a_t, a_prev = self.scheduler.coeffs(t)
+        if st.do_cfg:                                                              # :1157-1178 fused
+            u, c = noise_pred[:st.batch_size], noise_pred[st.batch_size:]
+            st.latents = ops.cfg_ddim_step(u, c, st.latents, self.guidance_scale, a_t, a_prev)
         else:
-            video_out = self.decode_latents(latents)
-        ev2.record()
-        if output_type in ("numpy", "np"):
-            video_out = video_out.cpu()                 # reference :517 / :1214 returns a CPU float tensor
-        self._events = (ev0, ev1, ev2)
-        self.maybe_free_model_hooks()
-        return CogVideoX_Fun_PipelineOutput(videos=video_out)
+            st.latents = ops.cfg_ddim_step(noise_pred, None, st.latents, 1.0, a_t, a_prev)
+        return st.latents
 
     def timings(self) -> Dict[str, float]:
         """Seconds spent in the denoise loop and in the VAE decode of the last call (syncs)."""

@@ -297,8 +297,8 @@ GEMM_BIAS, GEMM_BIAS_GELU, GEMM_GATED_RESIDUAL = 0, 1, 2
 
 
 def gemm_supported(N: int, K: int) -> bool:
-    """Shapes `tcx_gemm_bf16` takes (8-byte stores, two 64-deep K steps per iteration)."""
-    return N % 8 == 0 and K % 128 == 0
+    """Shapes `tcx_gemm_bf16` takes (16-byte rows of W / X and 16-byte stores); K % 128 != 0 runs its K-tail variant."""
+    return N % 8 == 0 and K % 8 == 0
 
 
 def _gemm_rows(t: torch.Tensor, name: str, N: int, M: int) -> Tuple[int, int, int]:
