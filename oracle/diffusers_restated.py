@@ -32,7 +32,7 @@ def timesteps_proj(timesteps: torch.Tensor, num_channels: int, flip_sin_to_cos: 
     """diffusers `Timesteps` / get_timestep_embedding: fp32 sinusoidal embedding."""
     assert timesteps.ndim == 1
     half = num_channels // 2
-    exponent = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32)
+    exponent = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32, device=timesteps.device)
     exponent = exponent / (half - downscale_freq_shift)
     emb = torch.exp(exponent)
     emb = timesteps[:, None].float() * emb[None, :]

@@ -119,6 +119,83 @@ def test_config_and_state_dict_round_trip(tmp_path):
         v.enable_tiling()
 
 
+def test_loaders_report_and_refuse_incomplete_checkpoints(tmp_path, capsys):
+    """A checkpoint that does not cover the model must not load silently (reference loaders only print counts, :952-973):
+    missing keys raise unless explicitly allowed, and the key names are printed."""
+    cfg = dict(num_attention_heads=2, num_layers=2, in_channels=33, text_embed_dim=32, time_embed_dim=32,
+               use_rotary_positional_embeddings=True, is_train_cross=True, cross_attn_dim_head=64, cross_attn_num_heads=2)
+    m = CrossTransformer3DModel(**cfg)
+    m.load_state_dict(iw.random_state_dict(iw.transformer_param_shapes(dict(m.config)), 3), strict=True)
+    d = tmp_path / "sharded"
+    m.save_pretrained(str(d), max_shard_size=200_000)                         # diffusers sharded layout + index.json
+    files = sorted(os.listdir(d))
+    assert "diffusion_pytorch_model.safetensors.index.json" in files and sum(f.endswith(".safetensors") for f in files) >= 3
+    m2 = CrossTransformer3DModel.from_pretrained(str(d))
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    # (1) a parameter of the base model missing -> error naming it, from every loader
+    from safetensors.torch import load_file, save_file
+    idx = json.load(open(d / "diffusion_pytorch_model.safetensors.index.json"))
+    victim = "transformer_blocks.1.ff.net.2.weight"
+    shard = idx["weight_map"][victim]
+    t = load_file(str(d / shard))
+    t.pop(victim)
+    save_file(t, str(d / shard))
+    for load in (CrossTransformer3DModel.from_pretrained, CrossTransformer3DModel.from_pretrained_2d,
+                 CrossTransformer3DModel.from_pretrained_cus):
+        with pytest.raises(RuntimeError, match="transformer_blocks.1.ff.net.2.weight"):
+            load(str(d))
+    assert victim in capsys.readouterr().out
+    assert CrossTransformer3DModel.from_pretrained(str(d), allow_missing=("transformer_blocks.1.ff.",)) is not None
+    # (2) the base CogVideoX-Fun checkpoint lacks the cross-attention modules this model adds: from_pretrained_2d / _cus accept
+    #     exactly that (the reference's use case), plain from_pretrained does not
+    base = {k: v for k, v in m.state_dict().items() if not k.startswith(CrossTransformer3DModel.NEW_CROSS_MODULES)}
+    b = tmp_path / "base"
+    os.makedirs(b)
+    save_file({k: v.contiguous() for k, v in base.items()}, str(b / "diffusion_pytorch_model.safetensors"))
+    json.dump(dict(m.config), open(b / "config.json", "w"))
+    m3 = CrossTransformer3DModel.from_pretrained_2d(str(b))
+    assert all(torch.equal(m3.state_dict()[k], v) for k, v in base.items())
+    assert "perceiver_cross_attention.0.to_q.weight" in capsys.readouterr().out
+    with pytest.raises(RuntimeError, match="perceiver_cross_attention"):
+        CrossTransformer3DModel.from_pretrained(str(b))
+    # (3) from_pretrained_cus(config_path=...): config.json read from another directory (reference :977-1003)
+    c = tmp_path / "cfgdir"
+    os.makedirs(c)
+    json.dump(dict(m.config, num_layers=1), open(c / "config.json", "w"))
+    m4 = CrossTransformer3DModel.from_pretrained_cus(str(b), config_path=str(c))
+    assert len(m4.transformer_blocks) == 1
+    with pytest.raises(RuntimeError, match="does not exist"):
+        CrossTransformer3DModel.from_pretrained_cus(str(b), config_path=str(tmp_path / "nowhere"))
+    # (4) a shape mismatch is an error for from_pretrained (diffusers semantics) unless ignore_mismatched_sizes
+    bad = dict(m.state_dict())
+    bad["proj_out.weight"] = torch.zeros(8, 128)
+    e = tmp_path / "bad"
+    os.makedirs(e)
+    save_file({k: v.contiguous() for k, v in bad.items()}, str(e / "diffusion_pytorch_model.safetensors"))
+    json.dump(dict(m.config), open(e / "config.json", "w"))
+    with pytest.raises(RuntimeError, match="proj_out.weight"):
+        CrossTransformer3DModel.from_pretrained(str(e))
+    assert CrossTransformer3DModel.from_pretrained(str(e), ignore_mismatched_sizes=True) is not None
+
+
+def test_add_noise_to_reference_video_matches_reference_formula():
+    """reference pipeline :163-175 (applied at :488-491 when transformer.config.add_noise_in_inpaint_model)."""
+    from trajectorycrafter_amd.models.pipeline_trajectorycrafter import add_noise_to_reference_video
+    img = torch.rand(2, 3, 5, 8, 8) * 2 - 1
+    img[:, :, :, :4] = -1.0                                              # masked-out pixels stay exactly -1
+    torch.manual_seed(9)
+    out = add_noise_to_reference_video(img, ratio=0.0563)
+    torch.manual_seed(9)
+    want = img + torch.where(img == -1, torch.zeros_like(img), torch.randn_like(img) * 0.0563)
+    assert torch.equal(out, want) and bool((out[:, :, :, :4] == -1).all()) and not torch.equal(out, img)
+    torch.manual_seed(9)
+    o2 = add_noise_to_reference_video(img)                               # ratio None: sigma = exp(N(-3, 0.5)) per sample
+    torch.manual_seed(9)
+    sigma = torch.exp(torch.normal(mean=-3.0, std=0.5, size=(2,)))
+    want2 = img + torch.where(img == -1, torch.zeros_like(img), torch.randn_like(img) * sigma[:, None, None, None, None])
+    assert torch.equal(o2, want2)
+
+
 def test_pipeline_rejects_cpu_models_and_checks_inputs():
     from trajectorycrafter_amd._lib import TcxError
     tr = CrossTransformer3DModel(num_attention_heads=2, num_layers=1, in_channels=33, text_embed_dim=32, time_embed_dim=32,

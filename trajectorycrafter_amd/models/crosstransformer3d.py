@@ -30,7 +30,7 @@ from torch import nn
 
 from .. import ops
 from .._lib import TcxError
-from ..config import ConfigMixin, ModelMixin, load_state_dict_from_dir, register_to_config
+from ..config import ConfigMixin, ModelMixin, load_checked, load_state_dict_from_dir, register_to_config
 
 BF16 = torch.bfloat16
 LOG2E = 1.4426950408889634
@@ -524,30 +524,48 @@ class CrossTransformer3DModel(ModelMixin, ConfigMixin):
         return Transformer2DModelOutput(sample=output)
 
     # ---- checkpoint loaders (:873-1092) ----
+    # parameters the reference adds on top of the CogVideoX-Fun checkpoint (`is_train_cross`, :565-579): the only ones a
+    # `from_pretrained_2d / _cus` checkpoint may legitimately lack (they keep their initialisation, as in the reference)
+    NEW_CROSS_MODULES = ("perceiver_cross_attention.", "ref_patch_embed.")
+
     @classmethod
-    def from_pretrained_2d(cls, pretrained_model_path, subfolder=None, transformer_additional_kwargs={}):
+    def from_pretrained_2d(cls, pretrained_model_path, subfolder=None, transformer_additional_kwargs={},
+                           allow_missing: Optional[Tuple[str, ...]] = None, _config_file: Optional[str] = None):
+        """reference :873-975: build from `config.json` (+ overriding kwargs), load `diffusion_pytorch_model.(bin|safetensors)`
+        or every `*.safetensors` shard, zero-pad / truncate the input channels of `patch_embed.proj.weight` when the
+        checkpoint was trained with another `in_channels` (:922-958), skip shape-mismatched keys with a message (:960-969).
+        Unlike the reference's silent `strict=False`, a missing parameter outside `allow_missing` (default: the cross-attention
+        modules this model adds to the base checkpoint) raises, and every skipped / missing key is printed by name."""
         if subfolder is not None:
             pretrained_model_path = os.path.join(pretrained_model_path, subfolder)
-        config_file = os.path.join(pretrained_model_path, "config.json")
+        config_file = _config_file or os.path.join(pretrained_model_path, "config.json")
         if not os.path.isfile(config_file):
             raise RuntimeError(f"{config_file} does not exist")
         with open(config_file) as f:
             config = json.load(f)
         model = cls.from_config(config, **transformer_additional_kwargs)
-        state_dict = load_state_dict_from_dir(pretrained_model_path)
+        state_dict = dict(load_state_dict_from_dir(pretrained_model_path))
         own = model.state_dict()
         key = "patch_embed.proj.weight"
-        if key in state_dict and state_dict[key].shape != own[key].shape:
-            # zero-pad or truncate the input channels of the patch embedding (:944-960)
-            new = torch.zeros_like(own[key])
-            c = min(new.shape[1], state_dict[key].shape[1])
-            new[:, :c] = state_dict[key][:, :c]
+        if key in state_dict and state_dict[key].shape != own[key].shape and state_dict[key].dim() == own[key].dim() \
+                and state_dict[key].shape[0] == own[key].shape[0] and state_dict[key].shape[2:] == own[key].shape[2:]:
+            new = torch.zeros_like(own[key])                                    # :944-958 (more channels: zero-fill the new ones;
+            c = min(new.shape[1], state_dict[key].shape[1])                     #           fewer: keep the leading ones)
+            new[:, :c] = state_dict[key][:, :c].to(new.dtype)
             state_dict[key] = new
-        filtered = {k: v for k, v in state_dict.items() if k in own and own[k].shape == v.shape}
-        skipped = sorted(set(state_dict) - set(filtered))
-        if skipped:
-            print(f"[from_pretrained_2d] skipped {len(skipped)} keys with no / mismatched destination")
-        model.load_state_dict(filtered, strict=False)
+        load_checked(model, state_dict, f"{cls.__name__}.from_pretrained_2d({pretrained_model_path})",
+                     cls.NEW_CROSS_MODULES if allow_missing is None else allow_missing, ignore_mismatched_sizes=True)
         return model
 
-    from_pretrained_cus = from_pretrained_2d
+    @classmethod
+    def from_pretrained_cus(cls, pretrained_model_path, subfolder=None, config_path=None, transformer_additional_kwargs={},
+                            allow_missing: Optional[Tuple[str, ...]] = None):
+        """reference :977-1092: `from_pretrained_2d` with the config optionally read from another directory (`config_path`)."""
+        if subfolder:
+            config_file = os.path.join(config_path or pretrained_model_path, subfolder, "config.json")
+        else:
+            config_file = os.path.join(config_path or pretrained_model_path, "config.json")
+        if not os.path.isfile(config_file):
+            raise RuntimeError(f"Configuration file '{config_file}' does not exist")
+        return cls.from_pretrained_2d(pretrained_model_path, subfolder, transformer_additional_kwargs, allow_missing,
+                                      _config_file=config_file)
