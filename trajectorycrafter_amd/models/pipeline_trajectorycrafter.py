@@ -183,26 +183,47 @@ class TrajCrafter_Pipeline:
         return self._interrupt
 
     # ---- prompt encoding (:248-381): conditioning I/O, runs the caller's T5 if one was given ----
+    def _get_t5_prompt_embeds(self, prompt=None, num_videos_per_prompt: int = 1, max_sequence_length: int = 226, device=None,
+                              dtype=None):
+        """reference :248-296: tokenizer (padded / truncated to `max_sequence_length`) -> text encoder -> [B,L,D]."""
+        if self.text_encoder is None or self.tokenizer is None:
+            raise ValueError("no text encoder: pass `prompt_embeds` / `negative_prompt_embeds` instead of `prompt`")
+        device = device or self._execution_device
+        dtype = dtype or self.text_encoder.dtype
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        batch_size = len(prompt)
+        text_input_ids = self.tokenizer(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
+                                        add_special_tokens=True, return_tensors="pt").input_ids
+        untruncated_ids = self.tokenizer(prompt, padding="longest", return_tensors="pt").input_ids
+        if untruncated_ids.shape[-1] >= text_input_ids.shape[-1] and not torch.equal(text_input_ids, untruncated_ids):
+            removed_text = self.tokenizer.batch_decode(untruncated_ids[:, max_sequence_length - 1:-1])
+            print("The following part of your input was truncated because `max_sequence_length` is set to "
+                  f" {max_sequence_length} tokens: {removed_text}")
+        prompt_embeds = self.text_encoder(text_input_ids.to(device))[0].to(dtype=dtype, device=device)
+        _, seq_len, _ = prompt_embeds.shape
+        prompt_embeds = prompt_embeds.repeat(1, num_videos_per_prompt, 1)
+        return prompt_embeds.view(batch_size * num_videos_per_prompt, seq_len, -1)
+
     def encode_prompt(self, prompt, negative_prompt=None, do_classifier_free_guidance=True, num_videos_per_prompt=1,
                       prompt_embeds=None, negative_prompt_embeds=None, max_sequence_length=226, device=None, dtype=None):
-        def embed(texts):
-            if self.text_encoder is None or self.tokenizer is None:
-                raise ValueError("no text encoder: pass `prompt_embeds` / `negative_prompt_embeds` instead of `prompt`")
-            ids = self.tokenizer(texts, padding="max_length", max_length=max_sequence_length, truncation=True,
-                                 add_special_tokens=True, return_tensors="pt").input_ids
-            return self.text_encoder(ids.to(device))[0].to(dtype=dtype or self.dtype, device=device)
-
+        """reference :298-381."""
+        device = device or self._execution_device
         prompt = [prompt] if isinstance(prompt, str) else prompt
         batch_size = len(prompt) if prompt is not None else prompt_embeds.shape[0]
         if prompt_embeds is None:
-            prompt_embeds = embed(prompt)
+            prompt_embeds = self._get_t5_prompt_embeds(prompt, num_videos_per_prompt, max_sequence_length, device, dtype)
         if do_classifier_free_guidance and negative_prompt_embeds is None:
             negative_prompt = negative_prompt or ""
             negative_prompt = batch_size * [negative_prompt] if isinstance(negative_prompt, str) else negative_prompt
-            if batch_size != len(negative_prompt):
-                raise ValueError(f"`negative_prompt` has batch size {len(negative_prompt)}, but `prompt` has batch size "
-                                 f"{batch_size}.")
-            negative_prompt_embeds = embed(negative_prompt)
+            if prompt is not None and type(prompt) is not type(negative_prompt):
+                raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} !="
+                                f" {type(prompt)}.")
+            elif batch_size != len(negative_prompt):
+                raise ValueError(f"`negative_prompt`: {negative_prompt} has batch size {len(negative_prompt)}, but `prompt`:"
+                                 f" {prompt} has batch size {batch_size}. Please make sure that passed `negative_prompt` matches"
+                                 " the batch size of `prompt`.")
+            negative_prompt_embeds = self._get_t5_prompt_embeds(negative_prompt, num_videos_per_prompt, max_sequence_length,
+                                                                device, dtype)
         return prompt_embeds, negative_prompt_embeds
 
     def check_inputs(self, prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs,
