@@ -55,6 +55,17 @@ def test_pipeline_two_steps_matches_oracle_and_reference(setup):
     assert float(frames.min()) >= 0 and float(frames.max()) <= 1
     ref_frames = opl.decode_latents(s["wv"], s["vae_cfg"], ref_lat, prec="bf16")
     _check_deep(frames, ref_frames, tp["frames"], "pipeline frames (denoise + VAE decode)")
+    # the measured worst-case error of the frames in [0, 1] against the REFERENCE's own fp32 frames (the fixture): the north
+    # star's rtol 1e-3 / atol 1e-4 is below bf16 resolution (one ulp of a value near 1 is 7.8e-3), so the stated bound is the
+    # one a bf16 execution can meet: no pixel off by more than max(2 x the oracle's bf16-contract worst case, 0.05) and the
+    # image-level error (mean abs) below 1 % of the [0, 1] range
+    e_hip, e_con = (frames - tp["frames"]).abs(), (ref_frames - tp["frames"]).abs()
+    rel = e_hip / tp["frames"].abs().clamp_min(1e-2)
+    print(f"frames vs reference fp32 fixture: max abs {float(e_hip.max()):.4f} (oracle bf16 contract {float(e_con.max()):.4f}), "
+          f"mean abs {float(e_hip.mean()):.5f}, max rel (|ref| >= 0.01) {float(rel.max()):.3f}, "
+          f"within 1e-3*|ref|+1e-4: {float((e_hip <= 1e-3 * tp['frames'].abs() + 1e-4).float().mean()):.3f}")
+    assert float(e_hip.max()) <= max(2.0 * float(e_con.max()), 0.05), (float(e_hip.max()), float(e_con.max()))
+    assert float(e_hip.mean()) <= 0.01
     # deterministic: same inputs -> bit-identical output
     assert torch.equal(s["pipe"](**kw).videos, frames)
 

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtcx_hip.so")
-SOURCES = ["tcx_api.cpp", "attn_fwd.hip", "norm.hip", "elementwise.hip", "conv.hip", "groupnorm.hip", "warp.hip", "gemm.hip"]
+SOURCES = ["tcx_api.cpp", "attn_fwd.hip", "norm.hip", "elementwise.hip", "conv.hip", "conv_mfma.hip", "groupnorm.hip", "warp.hip", "gemm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 

@@ -188,6 +188,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
 }  // namespace
 
+// TCX_CONV_GENERIC=1 (read once): run every conv on this file's register-staged kernel — A/B timing and parity cross-checks
+// of the two kernels; never set in production.
+#include <stdlib.h>
+static bool tcx_conv_force_generic() {
+    static const bool v = [] { const char* e = getenv("TCX_CONV_GENERIC"); return e && e[0] == '1'; }();
+    return v;
+}
+
 extern "C" int tcx_conv3d_cl(const void* x, const void* cache, const void* w, const void* bias, const void* res, void* y,
                              int32_t N, int32_t T_in, int32_t H_in, int32_t W_in, int32_t Cin, int32_t Cout,
                              int32_t kT, int32_t kH, int32_t kW, int32_t T_out, int32_t ups, int32_t stride,
@@ -207,6 +215,10 @@ extern "C" int tcx_conv3d_cl(const void* x, const void* cache, const void* w, co
     TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(cache) && tcx_aligned16(w) && tcx_aligned16(y) && tcx_aligned16(res) &&
                   (reinterpret_cast<uintptr_t>(bias) & 7) == 0,
               TCX_E_ALIGN, "tcx_conv3d_cl: pointers must be 16-byte aligned (bias 8)");
+    if (!tcx_conv_force_generic()) {
+        TcxConvArgs a{x, cache, w, bias, res, y, t_map, N, T_in, H_in, W_in, Cin, Cout, kT, kH, kW, T_out, ups, stride, pad_h, pad_w, H_out, W_out};
+        if (tcx_conv_mfma_supported(a)) return tcx_conv_mfma_launch(a, (hipStream_t)stream);   // LDS-DMA GEMM pipeline (conv_mfma.hip)
+    }
     ConvParams p;
     p.x = (const uint16_t*)x; p.cache = (const uint16_t*)cache; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias;
     p.res = (const uint16_t*)res; p.y = (uint16_t*)y; p.t_map = t_map;

@@ -59,6 +59,16 @@ static inline int tcx_ensure_dynamic_lds(TcxPerDeviceOnce& once, const void* fun
     return TCX_OK;
 }
 
+// ---- conv dispatch (conv.hip -> conv_mfma.hip) ----
+struct TcxConvArgs {
+    const void *x, *cache, *w, *bias, *res;
+    void* y;
+    const int32_t* t_map;
+    int32_t N, T_in, H_in, W_in, Cin, Cout, kT, kH, kW, T_out, ups, stride, pad_h, pad_w, H_out, W_out;
+};
+bool tcx_conv_mfma_supported(const TcxConvArgs& a);
+int tcx_conv_mfma_launch(const TcxConvArgs& a, hipStream_t st);
+
 // ---- device helpers ----
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
