@@ -41,7 +41,7 @@ struct ConvGemmParams {
     uint16_t* y;
     const int32_t* t_map;
     int64_t M, frame_elems;
-    int32_t T_in, W_in, Cin, Cout, kT, kH, kW, T_out, H, W, ups, LH, LW, stride, pad_h, pad_w, Ktot, mt, nt;
+    int32_t T_in, W_in, Cin, Cout, kT, kH, kW, T_out, H, W, ups, LH, LW, stride, pad_h, pad_w, Ktot, frames, mt, nt;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -65,13 +65,18 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(const ConvGemmParams p) 
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid / WN, wc = wid % WN;
 
-    // ---- tile of this workgroup (XCD-aware order as in gemm.hip: 4 m-tiles x all co-tiles per band) ----
-    constexpr int GM = 4;
+    // ---- tile of this workgroup ----
+    // Output frames (n, t) are tiled separately (tpf tiles of BM positions per frame, the last one ragged) and the tile order is
+    // co-tile fastest, then FRAME, then position: with the XCD remap (a contiguous range of the order per XCD) one XCD owns a
+    // spatial band across all frames, and the CUs working side by side read the same input rows — the 3 x 3 x 3 taps of
+    // neighbouring (t, y) tiles — out of that XCD's L2.  (Raster order gave every XCD a different frame: each input frame was then
+    // fetched by the three XCDs whose output frames read it, 3.6x the algorithmic bytes at the memory side.)
     const int t = (int)xcd_remap(blockIdx.x, gridDim.x);
-    const int band = t / (GM * p.nt), rr = t - band * (GM * p.nt);
-    const int gme = min(GM, p.mt - band * GM);
-    const int tm = band * GM + rr % gme, tn = rr / gme;
-    const int64_t m0 = (int64_t)tm * BM;
+    const int L = t / p.nt, tn = t - L * p.nt;
+    const int tj = L / p.frames, tf = L - tj * p.frames; // position tile tj of output frame tf = n * T_out + t
+    const int HW = p.H * p.W;
+    const int l0 = tj * BM;                              // first position of the tile inside its frame
+    const int64_t m0 = (int64_t)tf * HW + l0;
     const int n0 = tn * BN;
     const int KT = p.Ktot / BK;                          // even (host-checked)
 
@@ -84,14 +89,11 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(const ConvGemmParams p) 
         const int piece = (lane >> 3) & (2 * XP - 1);
         const int gq = piece / XP, gj = piece % XP;
         const int lr = (wid * XP + gj) * 8 + (lane & 7);
-        int64_t m = m0 + (lr >> 6) * 128 + gq * 64 + (lr & 63);
-        m = m < p.M ? m : p.M - 1;                       // rows past M gather a valid pixel; they are masked at the store
-        const int HW = p.H * p.W;
-        const int64_t fr = m / HW;
-        const int rem = (int)(m - fr * HW);
-        const int oy = rem / p.W, ox = rem - oy * p.W;
-        const int64_t n = fr / p.T_out;
-        const int tt = (int)(fr - n * p.T_out);
+        int loc = l0 + (lr >> 6) * 128 + gq * 64 + (lr & 63);
+        loc = loc < HW ? loc : HW - 1;                   // rows past the frame gather a valid pixel; they are masked at the store
+        const int oy = loc / p.W, ox = loc - oy * p.W;
+        const int64_t n = tf / p.T_out;
+        const int tt = tf - (int)n * p.T_out;
         g_t = (p.kT == 1 && p.t_map) ? p.t_map[tt] : tt; // t_map exists only for kT == 1 (upsample conv: nearest in time)
         g_oyp = oy * p.stride - p.pad_h;
         g_oxp = ox * p.stride - p.pad_w;
@@ -177,9 +179,13 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(const ConvGemmParams p) 
                 if (ci0 >= p.Cin) {                      // wave-uniform branch, every Cin / 64 K-tiles: next tap
                     ci0 = 0;
                     if (++tap_dx == p.kW) { tap_dx = 0; if (++tap_dy == p.kH) { tap_dy = 0; ++tap_dt; } }
+#ifndef TCX_CONV_EXP_NOTAP            // timing experiments only (wrong results): what a tap change costs
                     g_nxt = tap_pointer();
+#ifndef TCX_CONV_EXP_NOREFRESH
                     refresh_rows(IC<0>{});
                     tap_changed = true;
+#endif
+#endif
                 }
             }
         }
@@ -321,9 +327,9 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(const ConvGemmParams p) 
         u32x4 rr[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            int64_t m = m0 + wr * 128 + i * 8 + rl;
-            m = m < p.M ? m : p.M - 1;
-            rr[i] = *reinterpret_cast<const u32x4*>(p.res + m * p.Cout + nc8);
+            int loc = l0 + wr * 128 + i * 8 + rl;
+            loc = loc < HW ? loc : HW - 1;
+            rr[i] = *reinterpret_cast<const u32x4*>(p.res + ((int64_t)tf * HW + loc) * p.Cout + nc8);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -356,8 +362,8 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(const ConvGemmParams p) 
     for (int i = 0; i < 16; ++i) {
         const int row = i * 8 + rl;
         const u32x4 val = *reinterpret_cast<const u32x4*>(tile + row * 128 + ((ch ^ (row & 7)) << 4));
-        const int64_t m = m0 + wr * 128 + row;
-        if (m < p.M && nc8_ok) *reinterpret_cast<u32x4*>(p.y + m * p.Cout + nc8) = val;
+        const int loc = l0 + wr * 128 + row;
+        if (loc < HW && nc8_ok) *reinterpret_cast<u32x4*>(p.y + (m0 + wr * 128 + row) * p.Cout + nc8) = val;
     }
 }
 
@@ -392,7 +398,8 @@ int tcx_conv_mfma_launch(const TcxConvArgs& a, hipStream_t st) {
     p.frame_elems = (int64_t)a.H_in * a.W_in * a.Cin;
     const bool wide = a.Cout >= 256;                     // 256 x 256 tile; Cout == 128 (.. 255): 512 x 128
     const int BM = wide ? 256 : 512, BN = wide ? 256 : 128;
-    const int64_t mt = (p.M + BM - 1) / BM;
+    p.frames = a.N * a.T_out;
+    const int64_t mt = (int64_t)p.frames * (((int64_t)a.H_out * a.W_out + BM - 1) / BM);   // frames are tiled separately
     const int64_t nt = (a.Cout + BN - 1) / BN;
     TCX_CHECK(mt * nt < (1ll << 31) && p.M < (1ll << 40), TCX_E_SHAPE, "tcx_conv3d_cl: grid too large");
     p.mt = (int32_t)mt; p.nt = (int32_t)nt;
