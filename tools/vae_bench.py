@@ -54,6 +54,24 @@ if "shapes" in what:
         print(f"[{tag}] {name:34s} {dt * 1e3:8.3f} ms  {flop / dt / 1e12:7.1f} TFLOP/s", flush=True)
         del x, w, b, cache, r
 
+if "gn" in what:
+    g = torch.Generator(device=dev).manual_seed(0)
+    for name, C, T, H, W in (("up3 128ch 8x480x720", 128, 8, 480, 720), ("up2 256ch 8x240x360", 256, 8, 240, 360),
+                             ("up1 512ch 4x120x180", 512, 4, 120, 180), ("enc 128ch 9x480x720", 128, 9, 480, 720)):
+        x = torch.randn(1, T, H, W, C, device=dev, dtype=BF, generator=g)
+        gw, gb = torch.randn(C, device=dev, dtype=BF, generator=g), torch.randn(C, device=dev, dtype=BF, generator=g)
+        ytab = torch.randn(1, 2, 60, 90, C, device=dev, dtype=BF, generator=g)
+        btab = torch.randn(1, 2, 60, 90, C, device=dev, dtype=BF, generator=g)
+        tm = torch.tensor([(j * 2) // T for j in range(T)], dtype=torch.int32, device=dev)
+        nbytes = x.numel() * 2
+        ts = timed(lambda: ops.groupnorm_stats(x, 32, 1e-6), reps=10, warm=2)
+        st = ops.groupnorm_stats(x, 32, 1e-6)
+        ta = timed(lambda: ops.groupnorm_apply(x, st, gw, gb, 32, ytab, btab, tm, True), reps=10, warm=2)
+        tp = timed(lambda: ops.groupnorm_apply(x, st, gw, gb, 32, silu=True), reps=10, warm=2)
+        print(f"[gn] {name:22s} stats {ts * 1e6:7.1f} us ({nbytes / ts / 1e12:4.2f} TB/s)  apply+spatialnorm+silu {ta * 1e6:7.1f} us "
+              f"({2 * nbytes / ta / 1e12:4.2f} TB/s)  apply+silu {tp * 1e6:7.1f} us ({2 * nbytes / tp / 1e12:4.2f} TB/s)", flush=True)
+        del x
+
 vae = None
 if "decode" in what or "encode" in what:
     with torch.device("meta"):
