@@ -64,6 +64,23 @@ int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o,
                  int64_t v_stride_b, int64_t v_stride_s, int64_t v_stride_h,
                  int64_t o_stride_b, int64_t o_stride_s, int64_t o_stride_h,
                  float scale, int32_t flags, const float* k_sqmax, int32_t out_dtype, void* stream);
+/* Same call with a caller-owned scratch buffer (the product path).  With `workspace` (16-byte aligned, at least
+ * tcx_attn_fwd_workspace_bytes(...) bytes, contents irrelevant before and after) the bound-centred D = 64 launch balances its
+ * last, partly filled round of workgroups: the B*H*ceil(Sq/256) workgroups run in ceil(./#CU) rounds and the remainder (64 of
+ * 6720 on 256 CUs at 49f 480x720 = a quarter-filled 27th round) is cut into #CU/remainder parts along the keys; a part writes its
+ * un-normalised fp32 O and row sum to the workspace and a small second kernel adds the parts (every part exponentiates against
+ * the same origin |q| max|k|, so the combination is a plain sum).  Null / too small workspace: exactly tcx_attn_fwd.
+ * tcx_attn_fwd_workspace_bytes returns 0 when the call would not split (then no workspace is needed). */
+int64_t tcx_attn_fwd_workspace_bytes(int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t D, int32_t flags,
+                                     int32_t has_k_sqmax, int32_t out_dtype);
+int tcx_attn_fwd_ws(const void* q, const void* k, const void* v, void* o,
+                    int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t D,
+                    int64_t q_stride_b, int64_t q_stride_s, int64_t q_stride_h,
+                    int64_t k_stride_b, int64_t k_stride_s, int64_t k_stride_h,
+                    int64_t v_stride_b, int64_t v_stride_s, int64_t v_stride_h,
+                    int64_t o_stride_b, int64_t o_stride_s, int64_t o_stride_h,
+                    float scale, int32_t flags, const float* k_sqmax, int32_t out_dtype,
+                    void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- K2: per-head LayerNorm(D=64) on q and k + 3-D RoPE on the video tokens, in place ---------
  * Replaces: attn.norm_q / attn.norm_k (LayerNorm(64, eps 1e-6, affine)) and apply_rotary_emb on

@@ -125,6 +125,49 @@ def test_self_attention_shipped_path_fullsize(ops, gpu, rotary):
     assert torch.equal(ob[0], o[0]) and torch.equal(ob[1, :, :5], o[1, :, :5]) and torch.equal(ob[1, :, 6:], o[1, :, 6:])
 
 
+def test_self_attention_tail_split_fullsize(ops, gpu):
+    """The bound-centred launch cuts the workgroups of its last, partly filled round (6720 mod 256 = 64 of them at this
+    shape) into 4 key ranges and adds the parts (tcx_attn_fwd_ws, include/tcx_hip.h).  Against the single-pass launch
+    (split_tail=False): bit-identical on every workgroup that is not split; on the split ones only the fp32 summation order
+    differs (the parts share the exponent origin): |diff| <= 1 bf16 ulp of the value + 1e-4, and the same fp32-reference bound as
+    the unsplit kernel; a split workgroup that fails the M < 60 predicate is left to the exact kernel, bit for bit."""
+    lib = __import__("trajectorycrafter_amd._lib", fromlist=["load"]).load()
+    need = int(lib.tcx_attn_fwd_workspace_bytes(B, H, S, S, D, 1, 1, 0))
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    nwg = 70 * B * H
+    if nwg % cus == 0 or 2 * (nwg % cus) > cus:
+        assert need == 0
+        pytest.skip(f"no tail to split on a {cus}-CU device")
+    tail, split = nwg % cus, min(cus // (nwg % cus), 8)
+    assert need == (tail * split * 256 * (D + 1) + tail * split) * 4
+    g = torch.Generator(device=gpu).manual_seed(5)
+    q = torch.randn(B, S, H, D, device=gpu, dtype=BF, generator=g) * (D ** -0.5 * LOG2E)
+    k = torch.randn(B, S, H, D, device=gpu, dtype=BF, generator=g)
+    v = torch.randn(B, S, H, D, device=gpu, dtype=BF, generator=g)
+    ksq = (k.float() ** 2).sum(-1).amax(1).contiguous()
+    a = ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq)                          # product call: split
+    b_ = ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, split_tail=False)
+    same = (a == b_).flatten(3).all(-1)                                                   # [B,S,H] rows that agree bit for bit
+    blocks = same.view(B, -1, H)[:, : (S // 256) * 256].reshape(B, S // 256, 256, H).all(2)   # per (b, q-block, h), full blocks
+    n_diff = int((~blocks).sum()) + int(not bool(same[:, (S // 256) * 256:].all(1).all()))
+    assert 0 < n_diff <= tail, (n_diff, tail)                                              # only split workgroups may differ
+    d = (a.float() - b_.float()).abs()
+    assert bool((d <= b_.float().abs() * 2.0 ** -7 + 1e-4).all()), float(d.max())
+    bb, qq, hh = [int(x[0]) for x in torch.nonzero(~blocks, as_tuple=True)]                # one split workgroup: check it vs fp32
+    rows = torch.arange(qq * 256, qq * 256 + 256, 37, device=gpu)
+    ref = _softmax2_rows(q[bb, rows, hh], k[bb, :, hh], v[bb, :, hh])
+    err = (a[bb, rows, hh].float() - ref).abs()
+    assert float(err.max()) < 2e-3 and float(err.mean()) < 2.5e-4
+    # force that workgroup over the predicate: every part returns, the combine kernel skips it, the exact kernel computes it
+    q[bb, qq * 256 + 3: qq * 256 + 9, hh] = (q[bb, qq * 256 + 3: qq * 256 + 9, hh].float() * 6.0).to(BF)
+    c = ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq)
+    e = ops.attn_fwd(q, k, v, 1.0, log2_scores=True)
+    assert torch.equal(c[bb, qq * 256: qq * 256 + 256, hh], e[bb, qq * 256: qq * 256 + 256, hh])
+    assert torch.isfinite(c.float()).all()
+    # repeatable (parts are added in a fixed order)
+    assert torch.equal(c, ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq))
+
+
 def test_cross_attention_shipped_path_fullsize(ops, gpu):
     """PerceiverCrossAttention.forward's chain at q [2,17550,16,128] x k/v [2,4050,16,128] (k, v strided halves of one
     to_kv output as in the model) vs fp32 on sampled rows.  Tolerance as above (|o| ~ 1/sqrt(4050) ~ 1.6e-2)."""

@@ -23,6 +23,8 @@ SIGNATURES = {
     "tcx_last_error_string": [],
     "tcx_device_info": [C.c_int, C.POINTER(_i32)],
     "tcx_attn_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32] + [_i64] * 12 + [_f32, _i32, _vp, _i32, _vp],
+    "tcx_attn_fwd_ws": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32] + [_i64] * 12 + [_f32, _i32, _vp, _i32, _vp, _i64, _vp],
+    "tcx_attn_fwd_workspace_bytes": [_i32] * 8,
     "tcx_qk_layernorm_rope": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp],
     "tcx_layernorm_modulate": [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "tcx_gated_residual": [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _i64, _i32, _vp],
@@ -74,7 +76,8 @@ def load() -> C.CDLL:
             except AttributeError as e:
                 raise TcxError(f"libtcx_hip.so does not export {name}; rebuild it") from e
             fn.argtypes = argtypes
-            fn.restype = C.c_char_p if name == "tcx_last_error_string" else C.c_int
+            fn.restype = (C.c_char_p if name == "tcx_last_error_string" else
+                          C.c_int64 if name.endswith("_workspace_bytes") else C.c_int)
         _lib = lib
     return _lib
 

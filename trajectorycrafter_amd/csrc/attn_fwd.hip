@@ -44,7 +44,16 @@ struct AttnParams {
     float scale_log2;
     uint32_t nqb, nwg;
     const float* k_sqmax;   // [B*H] max_k |k|^2 (FAST path, optional): enables the bound-centred loop
+    // Tail split (bound-centred kernel only): the last `nwg - n_full` workgroups (what would run as a partly filled last
+    // round: nwg mod #CU) are each cut into `split` parts along the keys; a part writes its un-normalised O and row sum to
+    // `ws` and attn_combine_kernel adds the parts.  With the bound-centred softmax every part uses the same exponent origin
+    // M = |q| max|k|, so combining is a plain sum.  split <= 1: off.
+    float* ws;
+    size_t ws_bytes;
+    uint32_t n_full, split;
 };
+// workspace of the tail split: per item (tail workgroup x part): O [256][D] fp32, then l [256] fp32 per item, then one flag word
+__host__ __device__ inline size_t attn_ws_o_floats(uint32_t items, int D) { return (size_t)items * 256 * D; }
 
 #ifndef TCX_ATTN_SUM_MFMA
 #define TCX_ATTN_SUM_MFMA 0
@@ -82,7 +91,17 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    const uint32_t id = xcd_remap(blockIdx.x, p.nwg);
+    uint32_t pb = blockIdx.x;
+    int part = -1;                                   // >= 0: this workgroup computes part `part` of a split tail workgroup
+    uint32_t item = 0;
+    if constexpr (BOUND && !OUT_F32) {
+        if (p.split > 1 && pb >= p.n_full) {
+            item = pb - p.n_full;
+            part = (int)(item % p.split);
+            pb = p.n_full + item / p.split;
+        }
+    }
+    const uint32_t id = xcd_remap(pb, p.nwg);
     const uint32_t bh = id / p.nqb, qb = id - bh * p.nqb;
     const int b = bh / p.H, hd = bh - b * p.H;
     const int q0 = qb * (32 * NW) + wave * 32;
@@ -90,8 +109,16 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     // ---- K / V buffer descriptors: wave-uniform base, hardware range check at the end of row Sk-1 ----
     const uint16_t* kbase = p.k + (int64_t)b * p.ksb + (int64_t)hd * p.ksh;
     const uint16_t* vbase = p.v + (int64_t)b * p.vsb + (int64_t)hd * p.vsh;
-    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)((((int64_t)p.Sk - 1) * p.kss + D) * 2), 0x00020000);
-    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)((((int64_t)p.Sk - 1) * p.vss + D) * 2), 0x00020000);
+    int Sk = p.Sk;                                   // keys this workgroup sweeps: all, or the tiles of its part
+    if (part >= 0) {
+        const int T = (p.Sk + 63) >> 6;
+        const int t_lo = (int)((int64_t)part * T / p.split), t_hi = (int)((int64_t)(part + 1) * T / p.split);
+        kbase += (int64_t)t_lo * 64 * p.kss;
+        vbase += (int64_t)t_lo * 64 * p.vss;
+        Sk = min(p.Sk, t_hi * 64) - t_lo * 64;
+    }
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)((((int64_t)Sk - 1) * p.kss + D) * 2), 0x00020000);
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)((((int64_t)Sk - 1) * p.vss + D) * 2), 0x00020000);
     const int ktile_bytes = (int)(64 * p.kss * 2), vtile_bytes = (int)(64 * p.vss * 2);
 
     // ---- Q fragments: B operand, lane holds Q[q0 + r][16 ks + 8 h .. +8] ----
@@ -118,7 +145,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     constexpr int TPB = (D == 64) ? 2 : 1;  // 64-key tiles per barrier / staging round (D = 128 has no registers for 2)
     constexpr int R = 2 * TPB;              // LDS ring slots per operand; tile t lives in slot t % R
     u32x4 kreg[TPB][NLD], vreg[TPB][NLD];
-    const int ntiles = (p.Sk + 63) >> 6;
+    const int ntiles = (Sk + 63) >> 6;
 
     auto load_k = [&](auto jc, int tile) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;   // rows >= Sk read as zero (range check); tiles beyond the end too
@@ -207,6 +234,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             const float M = sqrtf(qsq * p.k_sqmax[bh]) * 1.002f + 1e-3f;
             const bool safe = __syncthreads_and(M < 60.0f) != 0;
             if constexpr (BOUND) {
+                if constexpr (!OUT_F32) {                // a split part tells the combine kernel whether it computed
+                    if (part >= 0 && tid == 0)
+                        reinterpret_cast<uint32_t*>(p.ws + attn_ws_o_floats(p.split * (p.nwg - p.n_full), D) + (size_t)p.split * (p.nwg - p.n_full) * 256)[item] = safe ? 1u : 0u;
+                }
                 if (!safe) return;
                 m = M;
                 first = false;
@@ -304,7 +335,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int kv = kv0 + 32 * t + (i & 3) + 8 * (i >> 2);
-                if (kv >= p.Sk) s[t][i] = -INFINITY;
+                if (kv >= Sk) s[t][i] = -INFINITY;
             }
     };
 
@@ -510,7 +541,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         if constexpr (FINE) tile_body_fine(std::true_type{}, prefetched, kbuf0 + decltype(slot_k)::value * TILEB, kb_after,
                                            vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
         else tile_body(std::true_type{}, kbuf0 + decltype(slot_k)::value * TILEB, vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
-        if (tile + 1 == ntiles - 1 && (p.Sk & 63)) mask_tail(nxt);
+        if (tile + 1 == ntiles - 1 && (Sk & 63)) mask_tail(nxt);
         if constexpr (!decltype(bnd)::value) row_max_and_rescale(nxt);   // bound-centred loop: the reference max never moves
         else __builtin_amdgcn_sched_barrier(0);                         // keep tiles apart (register pressure)
     };
@@ -583,7 +614,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     __syncthreads();
     qk_init(sa);
     qk_part(kbuf0, sa, 0, KS);
-    if (ntiles == 1 && (p.Sk & 63)) mask_tail(sa);
+    if (ntiles == 1 && (Sk & 63)) mask_tail(sa);
     if constexpr (!bounded) row_max_and_rescale(sa);
     __syncthreads();                      // slot 0 of K is overwritten at the end of the first super-step
 
@@ -614,6 +645,19 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         const uint32_t u = __float_as_uint(l);
         auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
         l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    if constexpr (BOUND && !OUT_F32) {
+        if (part >= 0) {                  // split part: un-normalised O (fp32) and the row sum go to the workspace
+            const uint32_t items = p.split * (p.nwg - p.n_full);
+            float* wo = p.ws + ((size_t)item * 256 + wave * 32 + r) * D;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<f32x4*>(wo + 32 * dt + 8 * i + 4 * h) = f32x4{o[dt][4 * i], o[dt][4 * i + 1], o[dt][4 * i + 2], o[dt][4 * i + 3]};
+            if (h == 0) p.ws[attn_ws_o_floats(items, D) + (size_t)item * 256 + wave * 32 + r] = l;
+            return;
+        }
     }
     const float inv = 1.0f / l;
     const int qrow = q0 + r;
@@ -668,6 +712,69 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     }
 }
 
+// Adds the parts of the split tail workgroups: O = sum_p O_p / sum_p l_p (same exponent origin in every part) -> bf16.
+// One block = 16 query rows x 16 threads (4 columns each, D = 64).
+__global__ __launch_bounds__(256) void attn_combine_kernel(const AttnParams p) {
+    constexpr int D = 64;
+    const uint32_t tail = p.nwg - p.n_full, items = tail * p.split;
+    const uint32_t w = blockIdx.x >> 4, rb = blockIdx.x & 15;
+    const uint32_t* flag = reinterpret_cast<const uint32_t*>(p.ws + attn_ws_o_floats(items, D) + (size_t)items * 256);
+    if (flag[w * p.split] == 0) return;              // not bound-safe: the exact kernel computes this workgroup
+    const uint32_t id = xcd_remap(p.n_full + w, p.nwg);
+    const uint32_t bh = id / p.nqb, qb = id - bh * p.nqb;
+    const int b = bh / p.H, hd = bh - b * p.H;
+    const int row = rb * 16 + (threadIdx.x >> 4), c = (threadIdx.x & 15) * 4;
+    const int q = qb * 256 + row;
+    if (q >= p.Sq) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
+    for (uint32_t part = 0; part < p.split; ++part) {
+        const size_t it = (size_t)w * p.split + part;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p.ws + (it * 256 + row) * D + c);
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+        l += p.ws[attn_ws_o_floats(items, D) + it * 256 + row];
+    }
+    const float inv = 1.0f / l;
+    u32x2 o;
+    o[0] = pack_bf16(acc[0] * inv, acc[1] * inv);
+    o[1] = pack_bf16(acc[2] * inv, acc[3] * inv);
+    *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.osb + (int64_t)q * p.oss + (int64_t)hd * p.osh + c) = o;
+}
+
+// number of CUs of the current device (cached per device ordinal; 0 on error)
+static uint32_t tcx_cu_count() {
+    static std::atomic<uint32_t> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    uint32_t n = cache[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = (uint32_t)v;
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+// Tail-split geometry of the bound-centred D = 64 bf16 launch: {tail workgroups, parts}; parts <= 1: no split.
+struct AttnSplit { uint32_t tail, split; };
+static AttnSplit attn_split_plan(int64_t nwg, int32_t Sk, uint32_t ncu) {
+    AttnSplit s{0, 1};
+    if (ncu == 0 || nwg < (int64_t)ncu) return s;    // fewer workgroups than CUs: nothing to balance
+    const uint32_t tail = (uint32_t)(nwg % ncu);
+    if (tail == 0 || tail * 2 > ncu) return s;       // the last round is at least half full
+    uint32_t split = ncu / tail;
+    const uint32_t ntiles = (uint32_t)((Sk + 63) >> 6);
+    if (split > 8) split = 8;
+    while (split > 1 && ntiles / split < 16) --split;   // a part should still amortise its prologue / epilogue
+    s.tail = tail;
+    s.split = split;
+    return s;
+}
+static size_t attn_ws_bytes(AttnSplit s, int D) {
+    const uint32_t items = s.tail * s.split;
+    return s.split > 1 ? (attn_ws_o_floats(items, D) + (size_t)items * 256 + items) * 4 : 0;
+}
+
 template <int D, bool F32, bool FAST, int NW, bool BOUND>
 int launch_one(AttnParams p, hipStream_t st) {
     constexpr int lds = 2 * (D == 64 ? 4 : 2) * 64 * D * 2;   // K ring + V ring, R slots each
@@ -676,7 +783,20 @@ int launch_one(AttnParams p, hipStream_t st) {
     if (arc != TCX_OK) return arc;
     p.nqb = (uint32_t)((p.Sq + 32 * NW - 1) / (32 * NW));
     p.nwg = p.nqb * (uint32_t)(p.B * p.H);
-    hipLaunchKernelGGL((attn_fwd_kernel<D, F32, FAST, NW, BOUND>), dim3(p.nwg), dim3(64 * NW), lds, st, p);
+    uint32_t grid = p.nwg;
+    float* ws = p.ws;
+    p.ws = nullptr; p.n_full = p.nwg; p.split = 1;
+    if constexpr (BOUND && !F32 && D == 64 && NW == 8) {
+        const AttnSplit sp = attn_split_plan(p.nwg, p.Sk, tcx_cu_count());
+        if (ws && sp.split > 1 && p.ws_bytes >= attn_ws_bytes(sp, D)) {
+            p.ws = ws; p.split = sp.split; p.n_full = p.nwg - sp.tail;
+            grid = p.n_full + sp.tail * sp.split;
+        }
+    }
+    hipLaunchKernelGGL((attn_fwd_kernel<D, F32, FAST, NW, BOUND>), dim3(grid), dim3(64 * NW), lds, st, p);
+    if constexpr (BOUND && !F32 && D == 64 && NW == 8) {
+        if (p.split > 1) hipLaunchKernelGGL(attn_combine_kernel, dim3((p.nwg - p.n_full) * 16), dim3(256), 0, st, p);
+    }
     TCX_LAUNCH_RET();
 }
 
@@ -693,11 +813,29 @@ int launch(const AttnParams& p, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int64_t tcx_attn_fwd_workspace_bytes(int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t D, int32_t flags,
+                                                int32_t has_k_sqmax, int32_t out_dtype) {
+    if (D != 64 || !(flags & TCX_ATTN_LOG2_SCORES) || !has_k_sqmax || out_dtype != TCX_BF16 || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return 0;
+    const int64_t nwg = (int64_t)((Sq + 255) / 256) * B * H;
+    return (int64_t)attn_ws_bytes(attn_split_plan(nwg, Sk, tcx_cu_count()), 64);
+}
+
 extern "C" int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o,
                             int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t D,
                             int64_t qsb, int64_t qss, int64_t qsh, int64_t ksb, int64_t kss, int64_t ksh,
                             int64_t vsb, int64_t vss, int64_t vsh, int64_t osb, int64_t oss, int64_t osh,
                             float scale, int32_t flags, const float* k_sqmax, int32_t out_dtype, void* stream) {
+    return tcx_attn_fwd_ws(q, k, v, o, B, H, Sq, Sk, D, qsb, qss, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, oss, osh, scale, flags, k_sqmax,
+                           out_dtype, nullptr, 0, stream);
+}
+
+extern "C" int tcx_attn_fwd_ws(const void* q, const void* k, const void* v, void* o,
+                               int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t D,
+                               int64_t qsb, int64_t qss, int64_t qsh, int64_t ksb, int64_t kss, int64_t ksh,
+                               int64_t vsb, int64_t vss, int64_t vsh, int64_t osb, int64_t oss, int64_t osh,
+                               float scale, int32_t flags, const float* k_sqmax, int32_t out_dtype,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+    TCX_CHECK(workspace == nullptr || (tcx_aligned16(workspace) && workspace_bytes >= 0), TCX_E_ALIGN, "tcx_attn_fwd: workspace must be 16-byte aligned");
     TCX_CHECK(q && k && v && o, TCX_E_NULL, "tcx_attn_fwd: null pointer");
     TCX_CHECK((flags & ~TCX_ATTN_LOG2_SCORES) == 0, TCX_E_SHAPE, "tcx_attn_fwd: unknown flags 0x%x", flags);
     const bool log2s = (flags & TCX_ATTN_LOG2_SCORES) != 0;
@@ -723,6 +861,7 @@ extern "C" int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o
     p.k_sqmax = log2s ? k_sqmax : nullptr;
     TCX_CHECK((uint64_t)((Sq + 127) / 128) * B * H < (1ull << 31), TCX_E_SHAPE, "tcx_attn_fwd: grid too large");
     p.nqb = 0; p.nwg = 0;       // set per launch geometry
+    p.ws = (float*)workspace; p.ws_bytes = workspace ? (size_t)workspace_bytes : 0; p.n_full = 0; p.split = 1;
     hipStream_t s = (hipStream_t)stream;
     if (D == 64 && log2s) return out_dtype == TCX_F32 ? launch<64, true, true>(p, s) : launch<64, false, true>(p, s);
     if (D == 64) return out_dtype == TCX_F32 ? launch<64, true, false>(p, s) : launch<64, false, false>(p, s);
