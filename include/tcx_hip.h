@@ -57,6 +57,12 @@ int tcx_device_info(int device, int32_t out[4]);
  *   rows whose bound is too large for that to be provably underflow-free use the exact tracking loop.
  * out_dtype: TCX_BF16 (product path) or TCX_F32 (test-only higher precision output). */
 #define TCX_ATTN_LOG2_SCORES 1
+/* TCX_ATTN_BOUND_PROVEN (with TCX_ATTN_LOG2_SCORES and k_sqmax): the caller GUARANTEES that 1.002 * |q_row| * sqrt(k_sqmax[b,h]) + 1e-3
+ * < 60 for every query row, e.g. analytically from the q/k LayerNorm parameters: |LN(x)|_2 <= sqrt(D), so |q| <= q_scale * (sqrt(D) *
+ * max|gamma_q| + |beta_q|_2), RoPE being a rotation (what CrossTransformer3D's Attention does, once per weight version).  The
+ * kernel then skips the per-workgroup test and the launch of the exact kernel on the (empty) complement: -63 us per call at the
+ * product shape.  A false guarantee cannot corrupt memory, but rows whose scores sit more than ~120 below the bound underflow. */
+#define TCX_ATTN_BOUND_PROVEN 2
 int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o,
                  int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t D,
                  int64_t q_stride_b, int64_t q_stride_s, int64_t q_stride_h,

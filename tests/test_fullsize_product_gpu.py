@@ -108,6 +108,10 @@ def test_self_attention_shipped_path_fullsize(ops, gpu, rotary):
     print(f"self-attention shipped path, sampled rows: max err {emax:.3e}, worst mean err {emean:.3e}")
     assert emax < 2e-3 and emean < 2.5e-4
 
+    # (2b) TCX_ATTN_BOUND_PROVEN (what the model passes when the LayerNorm parameters prove M < 60): no per-workgroup test, no
+    #      complement launch -> the same bits
+    assert torch.equal(ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True), o)
+
     # (3) one workgroup forced over the predicate: rows 1024..1030 of (b=1, h=5) scaled x6 -> M ~ 70 >= 60 for q-block 4
     #     (rows 1024..1279).  That workgroup must be computed by the complement launch = the exact-tracking kernel:
     #     bit-identical to the k_sqmax=None run there, while safe workgroups (different centring) are not all identical.

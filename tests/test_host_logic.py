@@ -196,6 +196,28 @@ def test_add_noise_to_reference_video_matches_reference_formula():
     assert torch.equal(o2, want2)
 
 
+def test_attention_bound_proof_from_layernorm_parameters():
+    """TCX_ATTN_BOUND_PROVEN is only passed when the q/k LayerNorm parameters prove |q| |k| < 60 for every input (|LN(x)|_2 <= 8)."""
+    from trajectorycrafter_amd.models.crosstransformer3d import Attention, LOG2E
+    a = Attention(query_dim=128, dim_head=64, heads=2)
+    qs = 64 ** -0.5 * LOG2E
+    assert a._bound_is_proven(qs)                                    # gamma = 1, beta = 0: 0.18 * 8 * 8 = 11.5
+    # the bound really bounds: random inputs through torch's LayerNorm never exceed it
+    with torch.no_grad():
+        a.norm_q.weight.mul_(1.3); a.norm_q.bias.add_(0.1); a.norm_k.weight.mul_(0.7); a.norm_k.bias.sub_(0.2)
+    assert a._bound_is_proven(qs)                                    # the in-place edits bumped the parameter versions
+    x = torch.randn(4096, 64) * torch.rand(4096, 1) * 50
+    nq = (a.norm_q(x) * qs).norm(dim=-1).max()
+    nk = a.norm_k(x).norm(dim=-1).max()
+    r = 8.0
+    bq = qs * float(r * a.norm_q.weight.abs().max() + a.norm_q.bias.norm())
+    bk = float(r * a.norm_k.weight.abs().max() + a.norm_k.bias.norm())
+    assert float(nq) <= bq and float(nk) <= bk and float(nq * nk) < 60
+    with torch.no_grad():
+        a.norm_k.weight.mul_(5.0)                                    # 0.18 * (8 * 1.3 + ..) * (8 * 3.5 + ..) > 60: no proof
+    assert not a._bound_is_proven(qs)
+
+
 def test_pipeline_rejects_cpu_models_and_checks_inputs():
     from trajectorycrafter_amd._lib import TcxError
     tr = CrossTransformer3DModel(num_attention_heads=2, num_layers=1, in_channels=33, text_embed_dim=32, time_embed_dim=32,

@@ -51,6 +51,7 @@ struct AttnParams {
     float* ws;
     size_t ws_bytes;
     uint32_t n_full, split;
+    uint32_t proven;        // TCX_ATTN_BOUND_PROVEN: the caller guarantees M < 60 for every row -> no predicate, no complement launch
 };
 // workspace of the tail split: per item (tail workgroup x part): O [256][D] fp32, then l [256] fp32 per item, then one flag word
 __host__ __device__ inline size_t attn_ws_o_floats(uint32_t items, int D) { return (size_t)items * 256 * D; }
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
             qsq = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
             const float M = sqrtf(qsq * p.k_sqmax[bh]) * 1.002f + 1e-3f;
-            const bool safe = __syncthreads_and(M < 60.0f) != 0;
+            const bool safe = p.proven ? true : __syncthreads_and(M < 60.0f) != 0;
             if constexpr (BOUND) {
                 if constexpr (!OUT_F32) {                // a split part tells the combine kernel whether it computed
                     if (part >= 0 && tid == 0)
@@ -805,7 +806,7 @@ int launch(const AttnParams& p, hipStream_t st) {
     if constexpr (FAST) {
         if (p.k_sqmax) {                                  // bound-centred kernel + exact kernel on the complement
             const int rc = launch_one<D, F32, true, 8, true>(p, st);
-            if (rc != TCX_OK) return rc;
+            if (rc != TCX_OK || p.proven) return rc;      // proven bound: every workgroup was bound-safe, the complement is empty
         }
     }
     return launch_one<D, F32, FAST, 8, false>(p, st);
@@ -837,8 +838,10 @@ extern "C" int tcx_attn_fwd_ws(const void* q, const void* k, const void* v, void
                                void* workspace, int64_t workspace_bytes, void* stream) {
     TCX_CHECK(workspace == nullptr || (tcx_aligned16(workspace) && workspace_bytes >= 0), TCX_E_ALIGN, "tcx_attn_fwd: workspace must be 16-byte aligned");
     TCX_CHECK(q && k && v && o, TCX_E_NULL, "tcx_attn_fwd: null pointer");
-    TCX_CHECK((flags & ~TCX_ATTN_LOG2_SCORES) == 0, TCX_E_SHAPE, "tcx_attn_fwd: unknown flags 0x%x", flags);
+    TCX_CHECK((flags & ~(TCX_ATTN_LOG2_SCORES | TCX_ATTN_BOUND_PROVEN)) == 0, TCX_E_SHAPE, "tcx_attn_fwd: unknown flags 0x%x", flags);
     const bool log2s = (flags & TCX_ATTN_LOG2_SCORES) != 0;
+    TCX_CHECK(!(flags & TCX_ATTN_BOUND_PROVEN) || (log2s && k_sqmax), TCX_E_SHAPE,
+              "tcx_attn_fwd: TCX_ATTN_BOUND_PROVEN needs TCX_ATTN_LOG2_SCORES and k_sqmax");
     TCX_CHECK(!log2s || scale == 1.0f, TCX_E_SHAPE, "tcx_attn_fwd: TCX_ATTN_LOG2_SCORES requires scale == 1 (got %g)", scale);
     TCX_CHECK(D == 64 || D == 128, TCX_E_SHAPE, "tcx_attn_fwd: head dim %d not in {64,128}", D);
     TCX_CHECK(B > 0 && H > 0 && Sq > 0 && Sk > 0, TCX_E_SHAPE, "tcx_attn_fwd: empty shape B=%d H=%d Sq=%d Sk=%d", B, H, Sq, Sk);
@@ -862,6 +865,7 @@ extern "C" int tcx_attn_fwd_ws(const void* q, const void* k, const void* v, void
     TCX_CHECK((uint64_t)((Sq + 127) / 128) * B * H < (1ull << 31), TCX_E_SHAPE, "tcx_attn_fwd: grid too large");
     p.nqb = 0; p.nwg = 0;       // set per launch geometry
     p.ws = (float*)workspace; p.ws_bytes = workspace ? (size_t)workspace_bytes : 0; p.n_full = 0; p.split = 1;
+    p.proven = (flags & TCX_ATTN_BOUND_PROVEN) ? 1u : 0u;
     hipStream_t s = (hipStream_t)stream;
     if (D == 64 && log2s) return out_dtype == TCX_F32 ? launch<64, true, true>(p, s) : launch<64, false, true>(p, s);
     if (D == 64) return out_dtype == TCX_F32 ? launch<64, true, false>(p, s) : launch<64, false, false>(p, s);

@@ -166,6 +166,7 @@ class Attention(nn.Module):
         self.to_out = nn.ModuleList([nn.Linear(inner, query_dim, bias=out_bias), nn.Dropout(0.0)])
         self.processor = processor or CogVideoXAttnProcessor2_0()
         self._fused: Optional[Tuple[Tuple[int, ...], torch.Tensor, Optional[torch.Tensor]]] = None
+        self._proven = None
 
     def get_processor(self):
         return self.processor
@@ -184,6 +185,22 @@ class Attention(nn.Module):
             self._fused = (key, w, b)
         return self._fused[1], self._fused[2]
 
+    def _bound_is_proven(self, q_scale: float) -> bool:
+        """True when the LayerNorm parameters alone prove the bound-centred attention loop safe for EVERY possible input:
+        |LN(x)|_2 <= sqrt(dh) (unit variance over dh elements), so |norm_q(x)| <= sqrt(dh) max|gamma_q| + |beta_q|_2 and likewise
+        for k; RoPE is a rotation.  With M = |q| |k| (q carrying q_scale) < 60 for all rows the kernel needs neither its per-
+        workgroup test nor the exact kernel's launch on the complement (TCX_ATTN_BOUND_PROVEN).  Evaluated once per weight
+        version (one host read of 4 x dh numbers); the 1.01 covers the bf16 rounding of q and k and the kernel's 1.002 margin."""
+        ws = (self.norm_q.weight, self.norm_q.bias, self.norm_k.weight, self.norm_k.bias)
+        key = tuple(w.data_ptr() for w in ws) + tuple(w._version for w in ws) + (q_scale,)
+        if self._proven is None or self._proven[0] != key:
+            with torch.no_grad():
+                gq, bq, gk, bk = (w.detach().float() for w in ws)
+                r = math.sqrt(self.dim_head)
+                bound = q_scale * float(r * gq.abs().max() + bq.norm()) * float(r * gk.abs().max() + bk.norm())
+            self._proven = (key, 1.01 * bound + 1e-3 < 60.0)
+        return self._proven[1]
+
     def forward(self, x_joint: torch.Tensor, text_len: int,
                 image_rotary_emb: Optional[Tuple[torch.Tensor, torch.Tensor]],
                 residual: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
@@ -198,9 +215,10 @@ class Attention(nn.Module):
         cos, sin = image_rotary_emb if image_rotary_emb is not None else (None, None)
         # q leaves the fused LN+RoPE kernel pre-multiplied by dh^-1/2 * log2(e): the attention kernel then
         # consumes base-2 scores (P = exp2(q k^T - max)), one FMA less per score in its VALU-bound loop
+        q_scale = dh ** -0.5 * LOG2E
         ksq = ops.qk_layernorm_rope(q, k, self.norm_q.weight, self.norm_q.bias, self.norm_k.weight, self.norm_k.bias,
-                                    cos, sin, text_len, self.eps, q_scale=dh ** -0.5 * LOG2E, want_k_sqmax=True)
-        o = ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq)          # [B,S,H,dh] contiguous
+                                    cos, sin, text_len, self.eps, q_scale=q_scale, want_k_sqmax=True)
+        o = ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=self._bound_is_proven(q_scale))   # [B,S,H,dh]
         if residual is not None:
             return _linear(o.view(B, S, D), self.to_out[0].weight, self.to_out[0].bias, ops.GEMM_GATED_RESIDUAL,
                            res=residual, gate_v=gate, gate_t=e_gate, text_len=text_len)

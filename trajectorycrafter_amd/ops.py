@@ -58,13 +58,15 @@ def attn_timing_stop() -> dict:
 
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
              out: Optional[torch.Tensor] = None, out_dtype=BF16, log2_scores: bool = False,
-             k_sqmax: Optional[torch.Tensor] = None, split_tail: bool = True) -> torch.Tensor:
+             k_sqmax: Optional[torch.Tensor] = None, split_tail: bool = True, bound_proven: bool = False) -> torch.Tensor:
     """q [B,Sq,H,D], k/v [B,Sk,H,D] bf16 views -> o [B,Sq,H,D].
 
     log2_scores: q k^T already is the base-2 exponent (q pre-multiplied by scale*log2(e)); scale must be 1.
     k_sqmax: fp32 [B,H] max_k |k|^2 from `qk_layernorm_rope` (log2_scores + D=64 only): bound-centred softmax loop.
     split_tail: let the bound-centred D = 64 launch split its last partly filled round of workgroups along the keys
-    (needs a scratch buffer, allocated here; False = the single-pass launch, for A/B runs and tests)."""
+    (needs a scratch buffer, allocated here; False = the single-pass launch, for A/B runs and tests).
+    bound_proven: the caller guarantees |q_row| * sqrt(k_sqmax) * 1.002 + 1e-3 < 60 for every row (TCX_ATTN_BOUND_PROVEN): no
+    per-workgroup test, no launch of the exact kernel on the complement."""
     for n, t in (("q", q), ("k", k), ("v", v)):
         _need(t, n)
     B, Sq, H, D = q.shape
@@ -83,7 +85,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
     if _ATTN_TIMING is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    flags = _lib.TCX_ATTN_LOG2_SCORES if log2_scores else 0
+    flags = (_lib.TCX_ATTN_LOG2_SCORES if log2_scores else 0) | (_lib.TCX_ATTN_BOUND_PROVEN if bound_proven else 0)
     odt = TCX_F32 if out_dtype == torch.float32 else TCX_BF16
     # scratch of the tail split (balances the last, partly filled round of workgroups; include/tcx_hip.h): caller-owned
     ws_bytes = int(lib.tcx_attn_fwd_workspace_bytes(B, H, Sq, Sk, D, flags, int(k_sqmax is not None), odt)) if split_tail else 0
