@@ -311,3 +311,31 @@ def test_configs2_full_model_two_steps_and_decode(gpu):
     assert lat.shape == (1, 13, 16, 60, 90) and lat.dtype == BF and torch.isfinite(lat.float()).all()
     # 2 of 50 steps from pure noise with random weights: the latents are still O(1) noise, not blown up or collapsed
     assert 0.3 < float(lat.float().std()) < 30.0         # (measured 3.7: guidance 6 on random-weight predictions)
+
+
+def test_oracle_on_device_equals_oracle_on_cpu(gpu):
+    """The full-size tests above evaluate the oracle's own functions on device tensors.  Same code, same fp32 arithmetic: at a
+    size the CPU finishes at once the two evaluations of a CogVideoXBlock + PerceiverCrossAttention agree to fp32 round-off, in
+    both precision modes (the CPU side is the one pinned by the reference fixtures, tests/test_oracle_golden.py)."""
+    from trajectorycrafter_amd import init_weights as iw
+    cfg = dict(otr.DEFAULT_CONFIG, num_attention_heads=4, num_layers=2, in_channels=33, text_embed_dim=64, time_embed_dim=64,
+               use_rotary_positional_embeddings=True, is_train_cross=True, cross_attn_dim_head=128, cross_attn_num_heads=2)
+    sd = {k: v.to(BF).float() for k, v in iw.random_state_dict(iw.transformer_param_shapes(cfg), seed=2).items()}
+    sdg = {k: v.to(gpu) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(3)
+    hidden, enc, temb = torch.randn(2, 3 * 4 * 6, 256, generator=g), torch.randn(2, 10, 256, generator=g), torch.randn(2, 64, generator=g)
+    ref_tokens = torch.randn(2, 48, 256, generator=g)
+    cos, sin = prepare_rotary(64, 96, 3, 2, 64)
+    for mode in ("fp32", "bf16"):
+        p = Prec(mode)
+        hc, ec = otr.cogvideox_block(p, sd, "transformer_blocks.0.", hidden, enc, temb, (cos, sin), 4, 1e-5)
+        hg, eg = otr.cogvideox_block(p, sdg, "transformer_blocks.0.", hidden.to(gpu), enc.to(gpu), temb.to(gpu), (cos.to(gpu), sin.to(gpu)), 4, 1e-5)
+        cc = otr.perceiver_cross_attention(p, sd, "perceiver_cross_attention.0.", ref_tokens, hc, 2, 128)
+        cg = otr.perceiver_cross_attention(p, sdg, "perceiver_cross_attention.0.", ref_tokens.to(gpu), hg, 2, 128)
+        for a, b in ((hc, hg), (ec, eg), (cc, cg)):
+            d = (a - b.cpu()).abs()
+            if mode == "fp32":
+                assert float(d.max()) <= 2e-5 * (1 + float(a.abs().max())), float(d.max())
+            else:   # a value on a bf16 rounding boundary may flip on fp32 round-off at any of the block's ~8 contract roundings
+                    # (measured: 0.5 % of the elements, one ulp): a few per cent at most, never more than one ulp + atol
+                assert float((d > 1e-5).float().mean()) < 3e-2 and bool((d <= a.abs() * 2.0 ** -7 + 1e-2).all()), (float(d.max()), float((d > 1e-5).float().mean()))

@@ -14,6 +14,7 @@ struct LnParams {
     int64_t msb;
     int32_t text_len;
     float eps;
+    int32_t rows_per_wave;     // row-looping kernel only (set by the launcher)
 };
 
 // NCH = 16-byte chunks per lane (C <= NCH * 512)
@@ -90,14 +91,13 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const LnParams p) {
 // for every load of x, and its loads die with the row.  Here a wave keeps its slices of the four parameter vectors in
 // registers (raw bf16), walks RPW rows of one segment (batch item x {text, video}: one modulation) and has the next row's
 // loads in flight while it reduces and writes the current one.  Same arithmetic, same order.
-constexpr int kLnRowsPerWave = 8;
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_modulate_rows_kernel(const LnParams p) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.y >> 1, vid = blockIdx.y & 1;
     const int seg0 = vid ? p.text_len : 0, seg1 = vid ? p.rows : p.text_len;
-    const int r0 = seg0 + (int)blockIdx.x * (4 * kLnRowsPerWave) + wv;     // this wave: r0, r0 + 4, ...
+    const int r0 = seg0 + (int)blockIdx.x * (4 * p.rows_per_wave) + wv;     // this wave: r0, r0 + 4, ...
     if (r0 >= seg1) return;
     const int nchunk = p.C >> 3;
     const uint16_t* sh = vid ? p.shift_v : p.shift_t;
@@ -124,10 +124,10 @@ __global__ __launch_bounds__(256) void ln_modulate_rows_kernel(const LnParams p)
         raw[j] = ch < nchunk ? *reinterpret_cast<const u32x4*>(xb + (int64_t)r0 * p.C + 8 * ch) : zero4;
     }
     const float invC = 1.0f / (float)p.C;
-    for (int i = 0; i < kLnRowsPerWave; ++i) {
+    for (int i = 0; i < p.rows_per_wave; ++i) {
         const int r = r0 + 4 * i;
         if (r >= seg1) break;
-        const bool more = i + 1 < kLnRowsPerWave && r + 4 < seg1;
+        const bool more = i + 1 < p.rows_per_wave && r + 4 < seg1;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int ch = j * 64 + lane;
@@ -195,6 +195,7 @@ struct QkParams {
     int64_t nvec;
     float q_scale;
     float* k_sqmax;
+    int32_t tokens_per_wave;   // token-per-wave kernel only (set by the launcher)
 };
 
 // 8 lanes per 64-wide head vector (8 bf16 = 16 B per lane); a wave covers 8 head vectors.
@@ -273,15 +274,14 @@ __global__ __launch_bounds__(256) void qk_ln_rope_kernel(const QkParams p) {
 // cos / sin are loaded once per token, gamma / beta once per wave, the 2 * NI row chunks of the next token are in flight
 // while the current one is normalised, and max |k|^2 is kept per head across the wave's tokens: one atomic per head
 // per wave instead of one per head vector.  Same arithmetic, same order as the kernel above.
-constexpr int kQkTokensPerWave = 8;
 
 template <int NI>
 __global__ __launch_bounds__(256) void qk_ln_rope_tok_kernel(const QkParams p) {
     const int lane = threadIdx.x & 63, sub = lane & 7, hs = lane >> 3;
     const int b = blockIdx.y;
-    const int s0 = ((int)blockIdx.x * 4 + (threadIdx.x >> 6)) * kQkTokensPerWave;
+    const int s0 = ((int)blockIdx.x * 4 + (threadIdx.x >> 6)) * p.tokens_per_wave;
     if (s0 >= p.S) return;
-    const int s1 = min(s0 + kQkTokensPerWave, p.S);
+    const int s1 = min(s0 + p.tokens_per_wave, p.S);
     uint16_t* qb = p.q + (int64_t)b * p.sb + 8 * sub;
     uint16_t* kb = p.k + (int64_t)b * p.sb + 8 * sub;
     const u32x4 rgq = *reinterpret_cast<const u32x4*>(p.gq + 8 * sub), rbq = *reinterpret_cast<const u32x4*>(p.bq + 8 * sub);
@@ -403,7 +403,14 @@ extern "C" int tcx_layernorm_modulate(const void* x, void* y, int32_t B, int32_t
     if (total >= 4096 && nch <= 6 && B <= 32767) {       // large inputs: row-looping kernel, parameters in registers
         const int tl = (shift_t || scale_t) ? text_len : 0;   // no text modulation: one segment per batch item
         p.text_len = tl;
-        const int seg = tl > rows - tl ? tl : rows - tl, per_block = 4 * kLnRowsPerWave;
+        // 8 rows per wave.  (Sizing the waves so that all working blocks are resident in ONE round — 18 rows at the product shape,
+        // 488 blocks on 512 slots instead of 1098 = 2.14 rounds — measured 11 % SLOWER in a same-box A/B, 0.126 vs 0.113 ms: waves
+        // that all start together load and compute in lockstep; the ragged multi-round schedule overlaps them.  The q/k LN + RoPE
+        // kernel below gains 5 % from the same sizing, tools/exp_norm.sh.)
+        const int seg = tl > rows - tl ? tl : rows - tl;
+        const int64_t rpw = 8;
+        p.rows_per_wave = (int32_t)rpw;
+        const int per_block = 4 * (int)rpw;
         dim3 g2((unsigned)((seg + per_block - 1) / per_block), (unsigned)(2 * B));
         if (nch <= 2) hipLaunchKernelGGL(ln_modulate_rows_kernel<2>, g2, block, 0, st, p);
         else if (nch <= 4) hipLaunchKernelGGL(ln_modulate_rows_kernel<4>, g2, block, 0, st, p);
@@ -439,7 +446,22 @@ extern "C" int tcx_qk_layernorm_rope(void* q, void* k, int32_t B, int32_t S, int
         if (me != hipSuccess) { tcx_set_error("tcx_qk_layernorm_rope: memset failed: %s", hipGetErrorString(me)); return (int)me; }
     }
     if (H == 48 && B <= 65535) {                         // the 5B model's head count: token-per-wave kernel
-        const int per_block = 4 * kQkTokensPerWave;
+        // tokens per wave: the kernel holds 192 VGPRs -> 2 waves per SIMD = 8 resident waves (2 blocks) per CU.  With a fixed 8
+        // tokens per wave the 2 x 17776 tokens of the product shape made 1112 blocks = 2.17 rounds of the 512 resident ones (a
+        // third round 17 % full: 28 % of the kernel idle).  Size the waves so that ALL of them are resident at once (one round,
+        // everybody finishes together); never fewer than 8 tokens (the per-wave parameter loads amortise over them).
+        int ncu = 256, dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        const int64_t resident_waves = (int64_t)(ncu > 0 ? ncu : 256) * 8;
+        int64_t tpw = ((int64_t)B * S + resident_waves - 1) / resident_waves;
+        // per-batch rounding: blocks are per batch item (blockIdx.y), 4 waves each
+        while (tpw < S && (int64_t)B * ((S + 4 * tpw - 1) / (4 * tpw)) * 4 > resident_waves) ++tpw;
+        if (tpw < 8) tpw = 8;
+#ifdef TCX_NORM_EXP_FIXED8
+        tpw = 8;
+#endif
+        p.tokens_per_wave = (int32_t)tpw;
+        const int per_block = 4 * (int)tpw;
         hipLaunchKernelGGL(qk_ln_rope_tok_kernel<6>, dim3((unsigned)((S + per_block - 1) / per_block), (unsigned)B), dim3(256), 0,
                            (hipStream_t)stream, p);
         TCX_LAUNCH_RET();
