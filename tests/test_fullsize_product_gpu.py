@@ -336,6 +336,8 @@ def test_oracle_on_device_equals_oracle_on_cpu(gpu):
             d = (a - b.cpu()).abs()
             if mode == "fp32":
                 assert float(d.max()) <= 2e-5 * (1 + float(a.abs().max())), float(d.max())
-            else:   # a value on a bf16 rounding boundary may flip on fp32 round-off at any of the block's ~8 contract roundings
-                    # (measured: 0.5 % of the elements, one ulp): a few per cent at most, never more than one ulp + atol
-                assert float((d > 1e-5).float().mean()) < 3e-2 and bool((d <= a.abs() * 2.0 ** -7 + 1e-2).all()), (float(d.max()), float((d > 1e-5).float().mean()))
+            else:   # a value on a bf16 rounding boundary may flip on fp32 round-off at any of the chain's contract roundings (measured:
+                    # 0.5 % of a block's outputs, one ulp each) and the flips feed the next op: never more than one ulp + atol, and a
+                    # mean difference far below the rounding step itself
+                assert bool((d <= a.abs() * 2.0 ** -7 + 1e-2).all()), float(d.max())
+                assert float(d.mean()) <= 2.0 ** -10 * float(a.abs().mean()), (float(d.mean()), float(a.abs().mean()))
