@@ -28,9 +28,12 @@ def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl" and os.environ.get("TCX_BENCH_SINGLE_DEVICE") != "1":
-            torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":
+            if os.environ.get("TCX_BENCH_SINGLE_DEVICE") != "1":
+                torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())   # binds the RCCL communicator to this rank's GPU
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
