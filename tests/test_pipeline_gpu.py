@@ -70,6 +70,35 @@ def test_pipeline_two_steps_matches_oracle_and_reference(setup):
     assert torch.equal(s["pipe"](**kw).videos, frames)
 
 
+def test_configs0_one_step_9_frames_256x256(setup):
+    """BASELINE configs[0] at its stated size: `TrajCrafter_Pipeline.__call__`, 1 denoise step, 9 frames 256x256 -> latent
+    [1,3,16,32,32] (Sv = 768 tokens), random latents + random render conditioning, CFG 6, seed-43 noise.  The
+    fixture weights are the reduced config SURVEY allows for committed checks; the oracle's fp32 run (the reference's maths) is the
+    exact side, its bf16 contract the comparison."""
+    s = setup
+    g = torch.Generator().manual_seed(43)
+    H = W = 256
+    video = torch.rand(1, 3, 9, H, W, generator=g)
+    blocks = (torch.rand(1, 1, 9, H // 32, W // 32, generator=g) < 0.3).float()
+    mask_video = torch.nn.functional.interpolate(blocks, size=(9, H, W)) * 255.0
+    reference = video[:, :, :9]
+    pe, ne = torch.randn(1, 226, 32, generator=g), torch.randn(1, 226, 32, generator=g)
+    lat0 = torch.randn(1, 3, 16, H // 8, W // 8, generator=g)
+    torch.manual_seed(1)
+    inpaint, ref = opl.build_conditioning(s["wv"], s["vae_cfg"], video, mask_video, reference, H, W, "fp32")
+    kw = dict(prompt=None, height=H, width=W, num_frames=9, num_inference_steps=1, guidance_scale=6.0, prompt_embeds=pe.to(BF),
+              negative_prompt_embeds=ne.to(BF), latents=lat0.to(BF), inpaint_latents=inpaint.to(BF), ref_latents=ref.to(BF))
+    lat = s["pipe"](output_type="latent", **kw).videos
+    args = (s["wt"], s["tr_cfg"], lat0.to(BF).float(), pe.to(BF).float(), ne.to(BF).float(), inpaint.to(BF).float(), ref.to(BF).float(), H, W, 1, 6.0)
+    con, ex = opl.denoise(*args, prec="bf16"), opl.denoise(*args, prec="fp32")
+    assert lat.shape == (1, 3, 16, 32, 32)
+    _check_deep(lat, con, ex, "configs[0]: 1 step, 9 frames 256x256, latents")
+    frames = s["pipe"](**kw).videos
+    assert frames.shape == (1, 3, 9, H, W) and frames.device.type == "cpu" and float(frames.min()) >= 0 and float(frames.max()) <= 1
+    _check_deep(frames, opl.decode_latents(s["wv"], s["vae_cfg"], con, prec="bf16"), opl.decode_latents(s["wv"], s["vae_cfg"], ex, prec="fp32"),
+                "configs[0]: frames")
+
+
 def test_pipeline_generator_and_no_cfg(setup):
     s, tp = setup, setup["tp"]
     g = torch.Generator("cpu").manual_seed(43)
