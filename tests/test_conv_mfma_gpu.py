@@ -101,6 +101,28 @@ def test_pointwise_shortcut_conv(ops, Cin, Cout):
     assert_bf16_close(y0, F.linear(x.float(), w.float()), atol=2e-3)
 
 
+@pytest.mark.parametrize("Cin,Cout,N,T,H,W", [(128, 3, 1, 3, 17, 23), (64, 3, 2, 2, 9, 10), (128, 4, 1, 1, 12, 31), (256, 2, 1, 2, 8, 8)])
+def test_narrow_output_conv(ops, Cin, Cout, N, T, H, W):
+    """Cout <= 4 (the decoder's conv_out, reference autoencoder_magvit.py:913,953): the dot-product kernel of csrc/conv.hip
+    (v_dot2c_f32_bf16, weights in LDS) — first chunk, cached chunk, ragged pixel count, batch 2."""
+    g = torch.Generator().manual_seed(Cin + Cout + T)
+    p = Prec("bf16")
+    w = bf(torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin))
+    b = bf(torch.randn(Cout, generator=g) * 0.1)
+    sd = {"c.conv.weight": w.float(), "c.conv.bias": b.float()}
+    x1, x2 = bf(torch.randn(N, Cin, T, H, W, generator=g)), bf(torch.randn(N, Cin, 2, H, W, generator=g))
+    cache = {}
+    r1 = ovae.causal_conv3d(p, sd, "c.", x1.float(), cache)
+    r2 = ovae.causal_conv3d(p, sd, "c.", x2.float(), cache)
+    dw, db = dev(w_cl(w)), dev(b)
+    d1, d2 = dev(to_cl(x1)), dev(to_cl(x2))
+    y1 = ops.conv3d_cl(d1, dw, db)
+    c = torch.cat([d1[:, :1], d1[:, :1], d1], 1)[:, -2:].contiguous()
+    y2 = ops.conv3d_cl(d2, dw, db, cache=c)
+    assert_bf16_close(from_cl(y1), r1, atol=2e-3)
+    assert_bf16_close(from_cl(y2), r2, atol=2e-3)
+
+
 def test_padding_reads_zeros_not_memory(ops):
     """Border taps must contribute exactly zero: with x = 1 everywhere and w = 1, y counts the in-range taps (27 inside, 18 on an
     edge, 12 in a corner; the causal context is the replicated first frame so time never truncates)."""

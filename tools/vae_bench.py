@@ -39,7 +39,7 @@ if "shapes" in what:
                                                   ("up1 resnet 256->256 3x3x3", 256, 256, 4, 120, 180, 3, 0, True),
                                                   ("up1 resnet0 512->256 3x3x3", 512, 256, 4, 120, 180, 3, 0, False),
                                                   ("up0 resnet 512->512 3x3x3", 512, 512, 2, 60, 90, 3, 0, True),
-                                                  ("conv_out 128->3(8) 3x3x3", 128, 8, 8, 480, 720, 3, 0, False)):
+                                                  ("conv_out 128->3 3x3x3", 128, 3, 8, 480, 720, 3, 0, False)):
         k = 3
         x = torch.randn(1, T, H, W, Cin, device=dev, dtype=BF, generator=g)
         w = torch.randn(Cout, kT, k if kT == 3 or ups else 1, k if kT == 3 or ups else 1, Cin, device=dev, dtype=BF, generator=g) / (27 * Cin) ** 0.5

@@ -186,6 +186,87 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 }
 
+// ---- narrow-output convolution (Cout <= 4: the decoder's conv_out, 128 -> 3 at full resolution) -------------------------------
+// An MFMA tile is at least 16 outputs wide (the kernels above: 128), so 3 output channels waste 81-97 % of the matrix work and,
+// worse, of the X staging: 3.6 ms per 8 x 480 x 720 chunk on the kernel above.  Here 8 lanes share one output pixel: lane
+// (lane & 7) owns the 16-byte channel chunk (lane & 7) of every 64-channel slice, so a wave-instruction reads 8 pixels x 128
+// contiguous bytes (full lines); the products run on v_dot2c_f32_bf16 (two bf16 MACs per lane-op, fp32 accumulate) against
+// the weights staged once per workgroup in LDS ([co][tap][ci], 20 KiB for 3 x 27 x 128), and the 8 partial sums of a pixel are
+// folded with DPP adds.  Padding taps are skipped per pixel (they contribute exact zeros).
+template <int CO>
+__global__ __launch_bounds__(256) void conv_narrow_kernel(const ConvParams p, int groups_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c8 = lane & 7, pl = lane >> 3;
+    const int ntap = p.kT * p.kH * p.kW, slices = p.Cin >> 6;
+    {   // weights -> LDS (same layout as global: [co][tap][ci])
+        const int n16 = p.Cout * ntap * p.Cin / 8;
+        for (int i = tid; i < n16; i += 256) reinterpret_cast<u32x4*>(wlds)[i] = reinterpret_cast<const u32x4*>(p.w)[i];
+    }
+    __syncthreads();
+    const int HW = p.H * p.W;
+    const int64_t frame_elems = (int64_t)p.H_in * p.W_in * p.Cin;
+    const int64_t g0 = ((int64_t)blockIdx.x * 4 + wave) * groups_per_wave;
+    for (int gi = 0; gi < groups_per_wave; ++gi) {
+        const int64_t m = (g0 + gi) * 8 + pl;                  // this lane group's output pixel
+        if ((g0 + gi) * 8 >= p.M) break;                        // wave-uniform
+        const bool live = m < p.M;
+        const int64_t mm = live ? m : p.M - 1;
+        const int64_t fr = mm / HW;
+        const int rem = (int)(mm - fr * HW);
+        const int oy = rem / p.W, ox = rem - oy * p.W;
+        const int n = (int)(fr / p.T_out), t = (int)(fr - (int64_t)n * p.T_out);
+        float acc[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+        for (int dt = 0; dt < p.kT; ++dt) {
+            const int li = t + dt;                              // logical input frame: kT - 1 context frames first
+            const uint16_t* fb;
+            if (li < p.kT - 1) fb = p.cache ? p.cache + ((int64_t)n * (p.kT - 1) + li) * frame_elems : p.x + (int64_t)n * p.T_in * frame_elems;
+            else fb = p.x + ((int64_t)n * p.T_in + (li - (p.kT - 1))) * frame_elems;
+            const uint16_t* centre = fb + ((int64_t)(oy - p.pad_h) * p.W_in + (ox - p.pad_w)) * p.Cin + 8 * c8;
+            for (int sl = 0; sl < slices; ++sl) {
+                // the 3 x 3 spatial taps of this frame and 64-channel slice: nine loads in flight, then 9 x CO x 4 dot products
+                u32x4 xv[9];
+#pragma unroll
+                for (int s9 = 0; s9 < 9; ++s9) {
+                    const int dy = s9 / 3, dx = s9 % 3;
+                    const bool ok = (unsigned)(oy + dy - p.pad_h) < (unsigned)p.LH && (unsigned)(ox + dx - p.pad_w) < (unsigned)p.LW;
+                    xv[s9] = u32x4{0u, 0u, 0u, 0u};
+                    if (ok) xv[s9] = *reinterpret_cast<const u32x4*>(centre + ((int64_t)dy * p.W_in + dx) * p.Cin + 64 * sl);
+                }
+#pragma unroll
+                for (int s9 = 0; s9 < 9; ++s9) {
+                    const int tap = dt * 9 + s9;
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) {
+                        if (co < p.Cout) {
+                            const u32x4 wv = *reinterpret_cast<const u32x4*>(wlds + (((size_t)co * ntap + tap) * p.Cin + 64 * sl + 8 * c8) * 2);
+                            // inline asm: with __builtin_amdgcn_fdot2_f32_bf16 on the elements of two u32x4 values hipcc (ROCm 7.2)
+                            // emitted all four products on element 0 (and loaded only that dword)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t xa = xv[s9][j], wa = wv[j];
+                                asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc[co]) : "v"(xa), "v"(wa));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = group8_sum(acc[co]);
+        if (live && c8 == 0) {
+#pragma unroll
+            for (int co = 0; co < CO; ++co)
+                if (co < p.Cout) {
+                    const float v = acc[co] + (p.bias ? bf16_bits_to_f32(p.bias[co]) : 0.f);
+                    p.y[m * p.Cout + co] = (uint16_t)(pack_bf16(v, 0.f) & 0xffff);
+                }
+        }
+    }
+}
+
 }  // namespace
 
 // TCX_CONV_GENERIC=1 (read once): run every conv on this file's register-staged kernel — A/B timing and parity cross-checks
@@ -219,6 +300,8 @@ extern "C" int tcx_conv3d_cl(const void* x, const void* cache, const void* w, co
         TcxConvArgs a{x, cache, w, bias, res, y, t_map, N, T_in, H_in, W_in, Cin, Cout, kT, kH, kW, T_out, ups, stride, pad_h, pad_w, H_out, W_out};
         if (tcx_conv_mfma_supported(a)) return tcx_conv_mfma_launch(a, (hipStream_t)stream);   // LDS-DMA GEMM pipeline (conv_mfma.hip)
     }
+    const bool narrow = !tcx_conv_force_generic() && Cout <= 4 && Cin % 64 == 0 && stride == 1 && ups == 0 && !t_map && !res &&
+                        kH == 3 && kW == 3 && H_out == H_in && W_out == W_in && (int64_t)Cout * kT * kH * kW * Cin * 2 <= 64 * 1024;
     ConvParams p;
     p.x = (const uint16_t*)x; p.cache = (const uint16_t*)cache; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias;
     p.res = (const uint16_t*)res; p.y = (uint16_t*)y; p.t_map = t_map;
@@ -231,6 +314,13 @@ extern "C" int tcx_conv3d_cl(const void* x, const void* cache, const void* w, co
     const int64_t nwg = ((p.M + BM - 1) / BM) * p.ntn;
     TCX_CHECK(nwg < (1ll << 31), TCX_E_SHAPE, "tcx_conv3d_cl: grid too large");
     p.nwg = (uint32_t)nwg;
+    if (narrow) {                                            // Cout <= 4: dot-product kernel, weights in LDS
+        const int gpw = 16;                                  // 8-pixel groups per wave: 512 pixels per workgroup
+        const int64_t nblk = (p.M + 4 * 8 * gpw - 1) / (4 * 8 * gpw);
+        TCX_CHECK(nblk < (1ll << 31), TCX_E_SHAPE, "tcx_conv3d_cl: grid too large");
+        hipLaunchKernelGGL(conv_narrow_kernel<4>, dim3((unsigned)nblk), dim3(256), (size_t)Cout * kT * kH * kW * Cin * 2, (hipStream_t)stream, p, gpw);
+        TCX_LAUNCH_RET();
+    }
     hipLaunchKernelGGL(conv_igemm_kernel, dim3(p.nwg), dim3(256), 0, (hipStream_t)stream, p);
     TCX_LAUNCH_RET();
 }
