@@ -210,9 +210,10 @@ def test_attention_bound_proof_from_layernorm_parameters():
     nq = (a.norm_q(x) * qs).norm(dim=-1).max()
     nk = a.norm_k(x).norm(dim=-1).max()
     r = 8.0
-    bq = qs * float(r * a.norm_q.weight.abs().max() + a.norm_q.bias.norm())
-    bk = float(r * a.norm_k.weight.abs().max() + a.norm_k.bias.norm())
-    assert float(nq) <= bq and float(nk) <= bk and float(nq * nk) < 60
+    with torch.no_grad():
+        bq = qs * float(r * a.norm_q.weight.abs().max() + a.norm_q.bias.norm())
+        bk = float(r * a.norm_k.weight.abs().max() + a.norm_k.bias.norm())
+        assert float(nq) <= bq and float(nk) <= bk and float(nq * nk) < 60
     with torch.no_grad():
         a.norm_k.weight.mul_(5.0)                                    # 0.18 * (8 * 1.3 + ..) * (8 * 3.5 + ..) > 60: no proof
     assert not a._bound_is_proven(qs)
