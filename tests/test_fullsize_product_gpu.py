@@ -292,6 +292,41 @@ def test_two_block_transformer_forward_fullsize_vs_oracle(gpu, rotary):
     _check_deep(got, con, ex, "full-size 2-block CrossTransformer3DModel.forward")
 
 
+def test_reference_default_resolution_384x672_full_model(gpu):
+    """The reference's own default sample size (demo.py / inference.py `--sample_size 384 672`; fractional RoPE grid positions,
+    SURVEY §8a row a8; S = 13 330 tokens, 53 q-blocks, 48 x 84 latents): the 42-layer model, 2 steps + decode, finite, in [0, 1],
+    bit-repeatable; and the 2-block forward at that size against the oracle."""
+    import bench
+    from trajectorycrafter_amd import init_weights as iw
+    from trajectorycrafter_amd.models.crosstransformer3d import CrossTransformer3DModel
+    args = argparse.Namespace(layers=42, frames=49, height=384, width=672)
+    pipe = bench.build_models(args, gpu)
+    inp = bench.make_inputs(args, gpu, seed=44)
+    kw = dict(prompt=None, height=384, width=672, num_frames=49, num_inference_steps=2, guidance_scale=6.0, output_type="pt", **inp)
+    a = pipe(**kw).videos
+    assert a.shape == (1, 3, 49, 384, 672) and torch.isfinite(a).all() and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    assert torch.equal(a, pipe(**kw).videos)
+    del pipe, a
+    cfg = dict(iw.TRANSFORMER_5B, num_layers=2)
+    sd32 = iw.random_state_dict(iw.transformer_param_shapes(dict(otr.DEFAULT_CONFIG, **cfg)), seed=0, dtype=torch.float32, device=gpu)
+    sd32 = {k: v.to(BF).float() for k, v in sd32.items()}
+    with torch.device("meta"):
+        model = CrossTransformer3DModel(**cfg)
+    model.load_state_dict({k: v.to(BF) for k, v in sd32.items()}, strict=True, assign=True)
+    model.eval()
+    cos, sin = prepare_rotary(384, 672, 13, 2, 64)
+    rot = (cos.to(gpu), sin.to(gpu))
+    g = torch.Generator(device=gpu).manual_seed(8)
+    rn = lambda *s: torch.randn(*s, device=gpu, dtype=BF, generator=g)
+    hs, txt, inp2, cross = rn(2, 13, 16, 48, 84), rn(2, 226, 4096), rn(2, 13, 17, 48, 84), rn(2, 3, 16, 48, 84)
+    ts = torch.tensor([499, 499], device=gpu)
+    with torch.no_grad():
+        got = model(hs, txt, ts, inpaint_latents=inp2, cross_latents=cross, image_rotary_emb=rot, return_dict=False)[0]
+        con = otr.transformer_forward(sd32, cfg, hs.float(), txt.float(), ts, inp2.float(), cross.float(), rot, prec="bf16")
+        ex = otr.transformer_forward(sd32, cfg, hs.float(), txt.float(), ts, inp2.float(), cross.float(), rot, prec="fp32")
+    _check_deep(got, con, ex, "384x672 2-block CrossTransformer3DModel.forward")
+
+
 def test_configs2_full_model_two_steps_and_decode(gpu):
     """BASELINE configs[2] smoke at full size: the 42-layer / 6.1 B-parameter model, 2 DDIM steps with CFG + the VAE decode to
     49 frames 480x720 through `TrajCrafter_Pipeline.__call__`: finite, in [0, 1], every frame differs (the decode used all
