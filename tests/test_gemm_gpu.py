@@ -55,7 +55,9 @@ def _check(got, want, scale=1.0):
                                    (300, 128, 128), (64, 384, 512), (100, 520, 128), (2, 64, 3072),
                                    # K-tail instantiation (K % 128 != 0: zero-filled last K-tile, odd tile counts)
                                    (300, 256, 32), (513, 264, 200), (260, 512, 136), (97, 64, 8), (300, 128, 192),
-                                   (2, 192, 64), (700, 520, 328)])
+                                   (2, 192, 64), (700, 520, 328),
+                                   # skinny kernel (M <= 8, bias epilogue): the AdaLN modulation / time-embedding Linears
+                                   (2, 18432, 512), (8, 1000, 200), (3, 6144, 512), (2, 512, 3072), (5, 64, 8)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_matches_oracle(ops, M, N, K, epi):
     g = torch.Generator().manual_seed(M * 7 + N + K + epi)

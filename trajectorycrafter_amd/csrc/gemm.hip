@@ -395,6 +395,63 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
     else store_rows(std::false_type{});
 }
 
+// ---- skinny GEMM: M <= 8 rows (the AdaLN modulation and time-embedding Linears: M = batch = 2, 85 launches per step) -----------
+// A 256 x 256 MFMA tile is 99 % padding there and costs ~15 us of pure latency (prologue + 8 K-tiles + epilogue).  This is a
+// weight-streaming kernel instead: 8 lanes share an output column (lane & 7 owns every 8th 16-byte chunk of the weight row:
+// a wave-instruction reads 8 rows x 128 contiguous bytes), x sits in LDS, products on v_dot2c_f32_bf16 (fp32 accumulate),
+// the 8 partial sums of a column are folded with DPP adds.  HBM-bound: N K 2 bytes of weights once.
+constexpr int kSkinnyMaxM = 8;
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char xl[];               // x rows: [M][K] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kp = lane & 7, nc = lane >> 3;
+    const int M = (int)p.M, kch = p.K >> 3;                                  // 16-byte chunks per row
+    for (int i = tid; i < M * kch; i += 256) {
+        const int m = i / kch, c = i - m * kch;
+        reinterpret_cast<u32x4*>(xl)[i] = *reinterpret_cast<const u32x4*>(p.x + (int64_t)m * p.ldx + 8 * c);
+    }
+    __syncthreads();
+    const int n = ((int)blockIdx.x * 4 + wave) * 8 + nc;
+    const int nn = n < p.N ? n : p.N - 1;
+    const uint16_t* wr = p.w + (int64_t)nn * p.K;
+    float acc[kSkinnyMaxM];
+#pragma unroll
+    for (int m = 0; m < kSkinnyMaxM; ++m) acc[m] = 0.f;
+    for (int c0 = kp; c0 < kch; c0 += 32) {                                  // four weight chunks in flight per lane
+        u32x4 wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 8 * u;
+            wv[u] = c < kch ? *reinterpret_cast<const u32x4*>(wr + 8 * c) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 8 * u;
+            if (c < kch) {
+#pragma unroll
+                for (int m = 0; m < kSkinnyMaxM; ++m) {
+                    if (m < M) {
+                        const u32x4 xv = *reinterpret_cast<const u32x4*>(xl + ((size_t)m * kch + c) * 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t xa = xv[j], wa = wv[u][j];
+                            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc[m]) : "v"(xa), "v"(wa));
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < kSkinnyMaxM; ++m) acc[m] = group8_sum(acc[m]);
+    if (kp == 0 && n < p.N) {
+        const float b = p.bias ? bf16_bits_to_f32(p.bias[n]) : 0.f;
+#pragma unroll
+        for (int m = 0; m < kSkinnyMaxM; ++m)
+            if (m < M) p.y[(int64_t)m * p.ldy + n] = (uint16_t)(pack_bf16(acc[m] + b, 0.f) & 0xffff);
+    }
+}
+
 template <int EPI, bool KTAIL>
 int launch_gemm_k(const GemmParams& p, hipStream_t st) {
     static TcxPerDeviceOnce lds_attr;          // hipFuncSetAttribute is per device: once per (kernel, device), thread-safe
@@ -446,6 +503,10 @@ extern "C" int tcx_gemm_bf16(const void* x, const void* w, const void* bias, voi
         p.gate_stride_b = gate_stride_b; p.text_len = text_len; p.res_stride_b = rows_per_batch > 0 ? res_stride_b : 0;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (epilogue == TCX_GEMM_BIAS && M <= kSkinnyMaxM && K % 8 == 0 && rows_per_batch == 0 && (size_t)M * K * 2 <= 64 * 1024) {
+        hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)((N + 31) / 32)), dim3(256), (size_t)M * K * 2, st, p);
+        TCX_LAUNCH_RET();
+    }
     switch (epilogue) {
         case TCX_GEMM_BIAS: return launch_gemm<0>(p, st);
         case TCX_GEMM_BIAS_GELU: return launch_gemm<1>(p, st);
