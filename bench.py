@@ -252,8 +252,18 @@ def run_rank(args):
     import torch.distributed as dist
     from trajectorycrafter_amd import dp, ops
 
+    backend = os.environ.get("TCX_DIST_BACKEND", "nccl")
     if world > 1:
-        dp.init_distributed(os.environ.get("TCX_DIST_BACKEND", "nccl"))
+        try:
+            dp.init_distributed(backend)
+        except Exception as e:                                  # RCCL unavailable on this node: the one gather of the path can
+            if backend != "nccl":                               # also go through gloo (host-mediated, ~0.2 s per clip); say so
+                raise
+            print(f"[bench] rank {rank}: RCCL init failed ({type(e).__name__}: {e}); falling back to gloo", file=sys.stderr, flush=True)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            backend = "gloo"
+            dp.init_distributed(backend)
     t_init = time.perf_counter()
     pipe = build_models(args, device)
     if args.graph is not None:
@@ -350,7 +360,7 @@ def run_rank(args):
                        "value_formula": "n_gpus / (denoise_steps * ms_per_step + decode_ms + allgather_ms) * 1000",
                        "frames": args.frames, "height": args.height, "width": args.width, "denoise_steps": args.denoise_steps,
                        "layers": args.layers, "vae_decode": not args.no_decode, "global_batch_clips": world,
-                       "parallelism": f"dp{world}", "decode_ms": 1e3 * decode_s, "allgather_ms": 1e3 * gather_s,
+                       "parallelism": f"dp{world}", "collective_backend": (backend if world > 1 else None), "decode_ms": 1e3 * decode_s, "allgather_ms": 1e3 * gather_s,
                        "clip_seconds": clip_s, "timed_steps_seconds": elapsed, "init_seconds": t_init,
                        "hip_graph": bool(getattr(pipe.transformer, "use_hip_graph", False)), "frames_out": frames_shape,
                        "transformer_mfma_frac": (None if fwd_flop is None else
