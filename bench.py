@@ -58,7 +58,6 @@ def parse(argv=None):
     ap.add_argument("--layers", type=int, default=42, help="(debug) fewer layers => NOT the benchmark config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="(debug) skip the VAE decode => NOT the benchmark config")
-    ap.add_argument("--graph", type=int, default=None, help="1/0: replay the transformer forward from a hipGraph (default: the pipeline's default)")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="(CPU test hook) run only the launcher + rank plumbing on gloo, no GPU, no model")
     return ap.parse_args(argv)
@@ -266,8 +265,6 @@ def run_rank(args):
             dp.init_distributed(backend)
     t_init = time.perf_counter()
     pipe = build_models(args, device)
-    if args.graph is not None:
-        pipe.transformer.use_hip_graph = bool(args.graph)
     inp = make_inputs(args, device, seed=43 + rank)            # one independent trajectory per rank (seeds 43..50)
     st = pipe.prepare_denoise(prompt=None, height=args.height, width=args.width, num_frames=args.frames,
                               num_inference_steps=args.denoise_steps, guidance_scale=6.0, **inp)
@@ -362,7 +359,7 @@ def run_rank(args):
                        "layers": args.layers, "vae_decode": not args.no_decode, "global_batch_clips": world,
                        "parallelism": f"dp{world}", "collective_backend": (backend if world > 1 else None), "decode_ms": 1e3 * decode_s, "allgather_ms": 1e3 * gather_s,
                        "clip_seconds": clip_s, "timed_steps_seconds": elapsed, "init_seconds": t_init,
-                       "hip_graph": bool(getattr(pipe.transformer, "use_hip_graph", False)), "frames_out": frames_shape,
+                       "frames_out": frames_shape,
                        "transformer_mfma_frac": (None if fwd_flop is None else
                                                  2 * fwd_flop * (args.layers / 42) / step_s / 1e12 / PEAK_BF16_TFLOPS)},
             "roofline": {"kernel": "tcx_attn_fwd<64> (joint self-attention, 42 launches per step)", "bound": "mfma",
