@@ -195,6 +195,20 @@ int tcx_conv3d_cl(const void* x, const void* cache, const void* w, const void* b
                   int32_t pad_h, int32_t pad_w, int32_t H_out, int32_t W_out, const int32_t* t_map,
                   void* stream);
 
+/* Which kernel tcx_conv3d_cl launches for a shape (host-only query, no GPU touched; the same decision function the launch
+ * uses).  Lets a caller / test assert that a model configuration reaches the kernels it was tuned for.
+ *   TCX_CONV_ROUTE_MFMA_WIDE  conv_mfma_kernel<2,4>: 256 x 256 tile, LDS-DMA gather (Cin % 64 == 0, Cout >= 256)
+ *   TCX_CONV_ROUTE_MFMA_TALL  conv_mfma_kernel<4,2>: 512 x 128 tile              (Cin % 64 == 0, 128 <= Cout < 256)
+ *   TCX_CONV_ROUTE_NARROW     conv_narrow_kernel: Cout <= 4 dot-product kernel   (the decoder's conv_out)
+ *   TCX_CONV_ROUTE_IGEMM      conv_igemm_kernel: register-staged 128 x 128 tile  (everything else)
+ * Replaces: nothing in the reference (cuDNN picks its algorithm internally behind nn.Conv3d, models/autoencoder_magvit.py:41-73). */
+#define TCX_CONV_ROUTE_MFMA_WIDE 1
+#define TCX_CONV_ROUTE_MFMA_TALL 2
+#define TCX_CONV_ROUTE_NARROW 3
+#define TCX_CONV_ROUTE_IGEMM 4
+int tcx_conv3d_route(int32_t T_in, int32_t H_in, int32_t W_in, int32_t Cin, int32_t Cout, int32_t kT, int32_t kH, int32_t kW,
+                     int32_t ups, int32_t stride, int32_t H_out, int32_t W_out, int32_t has_t_map, int32_t has_res);
+
 /* ---- temporal average pool of diffusers CogVideoXDownsample3D(compress_time) -------------------
  * x [N, T, S, C] channels-last bf16 (S = H*W) -> y [N, T', S, C]: T even: pairs averaged (T' = T/2);
  * T odd: frame 0 kept, frames 1.. averaged pairwise (T' = 1 + (T-1)/2).  fp32 mean, one rounding.

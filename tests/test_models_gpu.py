@@ -36,6 +36,19 @@ def _check(got, ref, ulps=2.0, atol=4e-3, mean_tol=2e-3):
     assert float(err.mean()) < mean_tol * (float(ref.abs().mean()) + 1e-6) + 1e-4, float(err.mean())
 
 
+def record_parity(rec: dict) -> None:
+    """Append a measured-tolerance record to gpurun_out/r3_parity.jsonl (merged back from the GPU box; DESIGN §4 quotes it)."""
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "r3_parity.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+
+
 def _check_deep(got, contract, exact, what):
     """Deep bf16 pipelines (many rounded layers) diverge element-wise even between two correct
     implementations, because a one-ulp flip early on is amplified downstream.  The criterion that
@@ -50,9 +63,16 @@ def _check_deep(got, contract, exact, what):
     msg = (f"{what}: mean|hip-exact| {float(e_hip.mean()):.3e}  mean|contract-exact| {float(e_con.mean()):.3e}  "
            f"mean|hip-contract| {float(e_hc.mean()):.3e}  p99.9 {q(e_hip):.3e} vs {q(e_con):.3e}  scale {float(exact.abs().mean()):.3e}")
     print(msg)
+    inside = lambda a, b: float(((a - b).abs() <= 1e-3 * b.abs() + 1e-4).float().mean())
+    rec = {"test": what, "scale": float(exact.abs().mean()),
+           "hip_vs_fp32": {"max": float(e_hip.max()), "mean": float(e_hip.mean()), "p99.9": q(e_hip), "inside_rtol1e-3_atol1e-4": inside(got, exact)},
+           "contract_vs_fp32": {"max": float(e_con.max()), "mean": float(e_con.mean()), "p99.9": q(e_con), "inside_rtol1e-3_atol1e-4": inside(contract, exact)},
+           "hip_vs_contract": {"max": float(e_hc.max()), "mean": float(e_hc.mean()), "inside_rtol1e-3_atol1e-4": inside(got, contract)}}
+    record_parity(rec)
     assert float(e_hip.mean()) <= 1.5 * float(e_con.mean()) + 1e-5, msg
     assert q(e_hip) <= 2.0 * q(e_con) + 1e-4, msg
     assert float(e_hc.mean()) <= 2.0 * float(e_con.mean()) + 1e-5, msg
+    return rec
 
 
 @pytest.fixture(scope="module")

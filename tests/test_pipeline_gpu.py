@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import pipeline as opl
-from tests.test_models_gpu import _check_deep, _weights
+from tests.test_models_gpu import _check_deep, _weights, record_parity as _record_parity
 
 BF = torch.bfloat16
 
@@ -66,6 +66,35 @@ def test_pipeline_two_steps_matches_oracle_and_reference(setup):
           f"within 1e-3*|ref|+1e-4: {float((e_hip <= 1e-3 * tp['frames'].abs() + 1e-4).float().mean()):.3f}")
     assert float(e_hip.max()) <= max(2.0 * float(e_con.max()), 0.05), (float(e_hip.max()), float(e_con.max()))
     assert float(e_hip.mean()) <= 0.01
+    # ---- the north-star tolerance, stated and measured (DESIGN §4 quotes these numbers; they are appended to
+    # gpurun_out/r3_parity.jsonl -> profiles/r3_parity.json) -------------------------------------------------------------------
+    # `Prec("bf16_ref")` = the reference's OWN eager bf16 execution (one rounding after every torch op).  Three bf16 executions
+    # of the same fp32 maths — the HIP path, the oracle's fused-rounding contract, the reference's per-op rounding — are
+    # compared with the reference's fp32 fixture and with each other.  What is asserted: (1) against fp32 the HIP frames are at
+    # least as close as the reference's own bf16 run (mean error <= 1.25x, share of pixels inside rtol 1e-3 / atol 1e-4 >= 0.8x
+    # its share); (2) the HIP frames are as close to the reference's bf16 run as the contract is (mean <= 1.5x).
+    ref16_lat = opl.denoise(s["wt"], s["tr_cfg"], tp["latents0"].to(BF).float(), tp["prompt_embeds"].to(BF).float(),
+                            tp["negative_prompt_embeds"].to(BF).float(), s["inpaint"].to(BF).float(), s["ref"].to(BF).float(),
+                            32, 48, 2, 6.0, prec="bf16_ref")
+    ref16_frames = opl.decode_latents(s["wv"], s["vae_cfg"], ref16_lat, prec="bf16_ref")
+    exact = tp["frames"]
+    inside = lambda a, b: float(((a - b).abs() <= 1e-3 * b.abs() + 1e-4).float().mean())
+    rec = {
+        "test": "pipeline_tiny 2-step CFG + decode, frames in [0,1] vs the reference's fp32 fixture",
+        "hip_vs_fp32": {"max": float(e_hip.max()), "mean": float(e_hip.mean()), "inside_rtol1e-3_atol1e-4": inside(frames, exact)},
+        "contract_vs_fp32": {"max": float(e_con.max()), "mean": float(e_con.mean()), "inside_rtol1e-3_atol1e-4": inside(ref_frames, exact)},
+        "bf16ref_vs_fp32": {"max": float((ref16_frames - exact).abs().max()), "mean": float((ref16_frames - exact).abs().mean()),
+                            "inside_rtol1e-3_atol1e-4": inside(ref16_frames, exact)},
+        "hip_vs_bf16ref": {"max": float((frames - ref16_frames).abs().max()), "mean": float((frames - ref16_frames).abs().mean()),
+                           "inside_rtol1e-3_atol1e-4": inside(frames, ref16_frames)},
+        "contract_vs_bf16ref": {"max": float((ref_frames - ref16_frames).abs().max()), "mean": float((ref_frames - ref16_frames).abs().mean()),
+                                "inside_rtol1e-3_atol1e-4": inside(ref_frames, ref16_frames)},
+    }
+    print("north-star tolerance, measured:", rec)
+    _record_parity(rec)
+    assert rec["hip_vs_fp32"]["mean"] <= 1.25 * rec["bf16ref_vs_fp32"]["mean"] + 1e-5, rec
+    assert rec["hip_vs_fp32"]["inside_rtol1e-3_atol1e-4"] >= 0.8 * rec["bf16ref_vs_fp32"]["inside_rtol1e-3_atol1e-4"], rec
+    assert rec["hip_vs_bf16ref"]["mean"] <= 1.5 * rec["contract_vs_bf16ref"]["mean"] + 1e-5, rec
     # deterministic: same inputs -> bit-identical output
     assert torch.equal(s["pipe"](**kw).videos, frames)
 

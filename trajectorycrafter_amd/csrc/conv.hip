@@ -277,6 +277,29 @@ static bool tcx_conv_force_generic() {
     return v;
 }
 
+// The ONE dispatch decision (tcx_conv3d_cl launches what this returns; tcx_conv3d_route reports it).
+static int conv_route(const TcxConvArgs& a) {
+    if (!tcx_conv_force_generic()) {
+        if (tcx_conv_mfma_supported(a)) return a.Cout >= 256 ? TCX_CONV_ROUTE_MFMA_WIDE : TCX_CONV_ROUTE_MFMA_TALL;
+        if (a.Cout <= 4 && a.Cin % 64 == 0 && a.stride == 1 && a.ups == 0 && !a.t_map && !a.res && a.kH == 3 && a.kW == 3 &&
+            a.H_out == a.H_in && a.W_out == a.W_in && (int64_t)a.Cout * a.kT * a.kH * a.kW * a.Cin * 2 <= 64 * 1024)
+            return TCX_CONV_ROUTE_NARROW;
+    }
+    return TCX_CONV_ROUTE_IGEMM;
+}
+
+extern "C" int tcx_conv3d_route(int32_t T_in, int32_t H_in, int32_t W_in, int32_t Cin, int32_t Cout, int32_t kT, int32_t kH,
+                                int32_t kW, int32_t ups, int32_t stride, int32_t H_out, int32_t W_out, int32_t has_t_map,
+                                int32_t has_res) {
+    static const int32_t dummy = 0;
+    TcxConvArgs a{};
+    a.t_map = has_t_map ? &dummy : nullptr;
+    a.res = has_res ? &dummy : nullptr;
+    a.N = 1; a.T_in = T_in; a.H_in = H_in; a.W_in = W_in; a.Cin = Cin; a.Cout = Cout; a.kT = kT; a.kH = kH; a.kW = kW;
+    a.T_out = T_in; a.ups = ups; a.stride = stride; a.H_out = H_out; a.W_out = W_out;
+    return conv_route(a);
+}
+
 extern "C" int tcx_conv3d_cl(const void* x, const void* cache, const void* w, const void* bias, const void* res, void* y,
                              int32_t N, int32_t T_in, int32_t H_in, int32_t W_in, int32_t Cin, int32_t Cout,
                              int32_t kT, int32_t kH, int32_t kW, int32_t T_out, int32_t ups, int32_t stride,
@@ -296,12 +319,11 @@ extern "C" int tcx_conv3d_cl(const void* x, const void* cache, const void* w, co
     TCX_CHECK(tcx_aligned16(x) && tcx_aligned16(cache) && tcx_aligned16(w) && tcx_aligned16(y) && tcx_aligned16(res) &&
                   (reinterpret_cast<uintptr_t>(bias) & 7) == 0,
               TCX_E_ALIGN, "tcx_conv3d_cl: pointers must be 16-byte aligned (bias 8)");
-    if (!tcx_conv_force_generic()) {
-        TcxConvArgs a{x, cache, w, bias, res, y, t_map, N, T_in, H_in, W_in, Cin, Cout, kT, kH, kW, T_out, ups, stride, pad_h, pad_w, H_out, W_out};
-        if (tcx_conv_mfma_supported(a)) return tcx_conv_mfma_launch(a, (hipStream_t)stream);   // LDS-DMA GEMM pipeline (conv_mfma.hip)
-    }
-    const bool narrow = !tcx_conv_force_generic() && Cout <= 4 && Cin % 64 == 0 && stride == 1 && ups == 0 && !t_map && !res &&
-                        kH == 3 && kW == 3 && H_out == H_in && W_out == W_in && (int64_t)Cout * kT * kH * kW * Cin * 2 <= 64 * 1024;
+    const TcxConvArgs a{x, cache, w, bias, res, y, t_map, N, T_in, H_in, W_in, Cin, Cout, kT, kH, kW, T_out, ups, stride, pad_h, pad_w, H_out, W_out};
+    const int route = conv_route(a);
+    if (route == TCX_CONV_ROUTE_MFMA_WIDE || route == TCX_CONV_ROUTE_MFMA_TALL)
+        return tcx_conv_mfma_launch(a, (hipStream_t)stream);                                   // LDS-DMA GEMM pipeline (conv_mfma.hip)
+    const bool narrow = route == TCX_CONV_ROUTE_NARROW;
     ConvParams p;
     p.x = (const uint16_t*)x; p.cache = (const uint16_t*)cache; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias;
     p.res = (const uint16_t*)res; p.y = (uint16_t*)y; p.t_map = t_map;

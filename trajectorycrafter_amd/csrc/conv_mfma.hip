@@ -306,6 +306,11 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(const ConvGemmParams p) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing LDS-DMA must land before the LDS is reused / released
     if (wid < 4) __builtin_amdgcn_s_barrier();           // balance the barrier count
+    // vmcnt(0) drains only the wave's OWN trailing LDS-DMA, and those pieces land in the buffer regions that are OTHER waves'
+    // epilogue tiles: every wave must have drained before any wave writes its tile (one workgroup-wide barrier, ~1 phase of wait
+    // for waves 0-3).
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 
     // ---- epilogue (gemm.hip): lane holds C[m = .. + fi][co = .. + 4 fg + 0..3] of each 16 x 16 tile ----
     int ncol[4];

@@ -254,6 +254,10 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
 #ifndef TCX_GEMM_EXP_NOSTAGGER
     if (wr == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count
 #endif
+    // A wave's vmcnt(0) covers only its OWN trailing LDS-DMA, whose pieces land in other waves' epilogue tiles (lds + wid * 16 KiB
+    // spans both K-tile buffers): every wave must have drained before any wave writes its tile.
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     // ---- epilogue: lane holds C[m = .. + fi][n = .. + 4 fg + 0..3] of each 16x16 tile ----
     // Branch-free loads (out-of-range rows / columns read a clamped, valid address; only the stores are predicated) so
     // that a row's residual and gate vectors are all in flight together instead of one L2 round trip each.

@@ -290,6 +290,14 @@ def conv3d_cl(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], ca
     return y
 
 
+def conv3d_route(Cin: int, Cout: int, k: Tuple[int, int, int] = (3, 3, 3), ups: int = 0, stride: int = 1,
+                 T: int = 2, H: int = 64, W: int = 64, t_map: bool = False, res: bool = False) -> int:
+    """Kernel `conv3d_cl` launches for this shape (TCX_CONV_ROUTE_*: 1 mfma 256x256, 2 mfma 512x128, 3 narrow, 4 igemm);
+    host-only query of the dispatch function itself."""
+    Ho, Wo = (H << ups, W << ups) if stride == 1 else ((H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1)
+    return int(_lib.load().tcx_conv3d_route(T, H, W, Cin, Cout, k[0], k[1], k[2], ups, stride, Ho, Wo, int(t_map or ups == 1), int(res)))
+
+
 def avgpool_t(x: torch.Tensor) -> torch.Tensor:
     """Temporal average pool of CogVideoXDownsample3D(compress_time): x [N,T,H,W,C] -> [N,T',H,W,C]."""
     _need(x, "x")
