@@ -171,6 +171,15 @@ int tcx_unpatchify(const void* x, void* out, int32_t B, int32_t F, int32_t C, in
 int tcx_cfg_ddim_step(const void* u, const void* c, const void* x, void* out, int64_t n,
                       float guidance, float alpha_t, float alpha_prev, int32_t pred_dtype, void* stream);
 
+/* ---- K10b: the same fusion for the reference's "DDIM_Cog" sampler (diffusers CogVideoXDDIMScheduler.step, eta = 0,
+ * v-prediction):  noise as above;  x0 = bf16r(sqrt_alpha_t * x) - sqrt_beta_t * noise;
+ *   x_prev = bf16r( bf16r(coef_sample * x) + coef_x0 * x0 ),   coef_sample = sqrt((1 - a_prev) / (1 - a_t)),
+ *   coef_x0 = sqrt(a_prev) - sqrt(a_t) * coef_sample — the four coefficients come from the scheduler's float64 tables (host).
+ * Replaces: models/pipeline_trajectorycrafter.py:1117,1157-1167,1178 with the scheduler demo.py:652 selects. */
+int tcx_cfg_ddim_cog_step(const void* u, const void* c, const void* x, void* out, int64_t n, float guidance,
+                          float sqrt_alpha_t, float sqrt_beta_t, float coef_sample, float coef_x0, int32_t pred_dtype,
+                          void* stream);
+
 /* ---- K11 / K12 / 1x1x1 convs: bf16 implicit-GEMM convolution, channels-last -------------------
  * y[n, t, oy, ox, co] = bias[co] + sum_{dt,dy,dx,ci} X(t + dt, oy*stride + dy - pad_h, ox*stride + dx - pad_w, ci)
  *                                                    * w[co, dt, dy, dx, ci]   (+ res[n,t,oy,ox,co])

@@ -359,3 +359,49 @@ class DDIMScheduler:
             raise ValueError(self.prediction_type)
         direction = (1 - a_prev) ** 0.5 * eps
         return a_prev ** 0.5 * x0 + direction
+
+
+class CogVideoXDDIMScheduler(DDIMScheduler):
+    """diffusers `CogVideoXDDIMScheduler` (the reference's "DDIM_Cog", demo.py:652), restated from the published algorithm
+    (parity unpinned like the rest of this file): float64 schedule, `alphas_cumprod / (s + (1 - s) alphas_cumprod)` SNR shift,
+    then `rescale_zero_terminal_snr` on alphas_cumprod itself; `step` in the a_t / b_t form:
+
+        x0 = sqrt(a_t) x - sqrt(1 - a_t) v;   a = sqrt((1 - a_prev) / (1 - a_t));   b = sqrt(a_prev) - sqrt(a_t) a
+        x_prev = a x + b x0
+
+    Defaults as scheduler.CogVideoXDDIMScheduler (CogVideoX-5b scheduler_config.json as recalled)."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 prediction_type="v_prediction", timestep_spacing="trailing", rescale_betas_zero_snr=True,
+                 set_alpha_to_one=True, steps_offset=0, clip_sample=False, snr_shift_scale=1.0):
+        super().__init__(num_train_timesteps, beta_start, beta_end, beta_schedule, prediction_type, timestep_spacing,
+                         rescale_betas_zero_snr, set_alpha_to_one, steps_offset, clip_sample)
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float64) ** 2
+        alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        alphas_cumprod = alphas_cumprod / (snr_shift_scale + (1 - snr_shift_scale) * alphas_cumprod)
+        if rescale_betas_zero_snr:
+            alphas_bar_sqrt = alphas_cumprod.sqrt()
+            a0, aT = alphas_bar_sqrt[0].clone(), alphas_bar_sqrt[-1].clone()
+            alphas_bar_sqrt = alphas_bar_sqrt - aT
+            alphas_bar_sqrt = alphas_bar_sqrt * (a0 / (a0 - aT))
+            alphas_cumprod = alphas_bar_sqrt ** 2
+        self.betas = betas
+        self.alphas_cumprod = alphas_cumprod
+        self.final_alpha_cumprod = torch.tensor(1.0, dtype=torch.float64) if set_alpha_to_one else alphas_cumprod[0]
+
+    def step(self, p: Prec, model_output: torch.Tensor, timestep: int, sample: torch.Tensor, eta: float = 0.0):
+        """0-dim float64 scalars times a bf16 tensor stay bf16 (the same promotion quirk as DDIMScheduler.step): sqrt(a_t) x and
+        a x are rounded before they meet the fp32 terms."""
+        assert eta == 0.0
+        a_t, a_prev = self.coeffs(int(timestep))
+        s = sample.float()
+        f = lambda v: float(v)                               # fp64 scalar -> the fp32 op-math scalar torch multiplies with
+        if self.prediction_type == "v_prediction":
+            x0 = p.R(f(a_t ** 0.5) * s) - f((1 - a_t) ** 0.5) * model_output
+        elif self.prediction_type == "epsilon":
+            x0 = (s - f((1 - a_t) ** 0.5) * model_output) / f(a_t ** 0.5)
+        else:
+            raise ValueError(self.prediction_type)
+        a = ((1 - a_prev) / (1 - a_t)) ** 0.5
+        b = a_prev ** 0.5 - a_t ** 0.5 * a
+        return p.R(f(a) * s) + f(b) * x0

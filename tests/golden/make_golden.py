@@ -457,9 +457,47 @@ def make_warp():
          dict(source="reference models/utils.py Warper.forward_warp(frame, None, depth, t1, t2, K, None, False, twice=False)", seed=4242))
 
 
+def _stub_utils_imports():
+    import importlib
+    for name in ("cv2", "decord", "skimage", "skimage.io", "torchvision", "torchvision.transforms", "PIL", "PIL.Image",
+                 "matplotlib", "matplotlib.pyplot", "tqdm", "imageio"):
+        try:
+            importlib.import_module(name)
+        except Exception:
+            _mod(name, VideoReader=object, cpu=lambda *a: None, imread=None, ToTensor=object, Image=object)
+
+
+def make_poses():
+    """orbit_poses.safetensors: the reference's own `generate_traj_specified` (models/utils.py:134-158, with `sphere2pose`
+    :83-131) on the eight target poses of inference_orbits.py:258-283, at radius 1.0 and at the clamped / scaled radii
+    `get_poses` (demo.py:538-586) produces for a centre depth of 2.5 and 7.0 (-> min(radius, 5)); 49 frames, plus one variant
+    that also moves in x / y / r (d_x, d_y are unused by the orbit set but part of the function)."""
+    if not os.path.isdir(REF):
+        raise SystemExit("make_golden.py needs /root/reference (build container only)")
+    _stub_utils_imports()
+    sys.path.insert(0, REF)
+    from models.utils import generate_traj_specified
+    c2w_init = torch.tensor([[-1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, -1.0, 0.0], [0.0, 0.0, 0.0, 1.0]]).unsqueeze(0)
+    variants = [[0, -30, 1.0, 0, 0], [0, 30, 1.0, 0, 0], [30, 0, 1.0, 0, 0], [0, -45, 1.0, 0, 0], [0, 45, 1.0, 0, 0],
+                [45, 0, 1.0, 0, 0], [0, -90, 1.0, 0, 0], [0, 90, 1.0, 0, 0], [10, -20, 0.5, 0.3, -0.2]]
+    out = {}
+    for radius in (1.0, 2.5, 5.0):
+        ps = []
+        for th, ph, dr, dx, dy in variants:
+            ps.append(generate_traj_specified(c2w_init, th, ph, dr * radius, dx, dy, 49, "cpu"))
+        out[f"poses_r{radius}"] = torch.stack(ps).float()
+    out["variants"] = torch.tensor(variants, dtype=torch.float32)
+    save("orbit_poses.safetensors", out,
+         dict(source="reference models/utils.py generate_traj_specified(c2w_init, theta, phi, d_r * radius, d_x, d_y, 49, 'cpu')",
+              frames=49))
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["warp"]:
         make_warp()
+    elif sys.argv[1:] == ["poses"]:
+        make_poses()
     else:
         main()
         make_warp()
+        make_poses()

@@ -45,6 +45,57 @@ def test_scheduler_from_pretrained(tmp_path):
     assert s.timesteps[0] == 999
 
 
+def test_cog_scheduler_matches_oracle_and_sampler_table(tmp_path):
+    """`DDIM_Cog` (demo.py:652): product tables / step coefficients == the oracle's, float64; the sampler table of
+    `trajectorycrafter_amd.run` resolves the reference's names, reads scheduler/scheduler_config.json, and says which of the
+    reference's choices are not built."""
+    from trajectorycrafter_amd.run import make_scheduler
+    from trajectorycrafter_amd.scheduler import CogVideoXDDIMScheduler
+    a, b = CogVideoXDDIMScheduler(), dr.CogVideoXDDIMScheduler()
+    assert a.alphas_cumprod.dtype == torch.float64 and torch.equal(a.alphas_cumprod, b.alphas_cumprod)
+    a3, b3 = CogVideoXDDIMScheduler(snr_shift_scale=3.0), dr.CogVideoXDDIMScheduler(snr_shift_scale=3.0)
+    assert torch.equal(a3.alphas_cumprod, b3.alphas_cumprod) and not torch.equal(a3.alphas_cumprod, a.alphas_cumprod)
+    assert a3.config.snr_shift_scale == 3.0 and a.config.timestep_spacing == "trailing"
+    for n in (2, 50):
+        a.set_timesteps(n), b.set_timesteps(n)
+        assert a.timesteps.tolist() == b.timesteps.tolist()
+        for t in a.timesteps.tolist():
+            sa, sb, ca, cb = a.step_coeffs(t)
+            at, ap = b.coeffs(t)
+            assert sa == float(at ** 0.5) and sb == float((1 - at) ** 0.5)
+            assert ca == float(((1 - ap) / (1 - at)) ** 0.5) and cb == float(ap ** 0.5 - at ** 0.5 * ((1 - ap) / (1 - at)) ** 0.5)
+    sa, sb, ca, cb = a.step_coeffs(a.timesteps.tolist()[-1])
+    assert ca == 0.0 and cb == 1.0                              # the last step lands on x0 (final alpha = 1)
+    assert type(make_scheduler("DDIM_Origin", None)) is DDIMScheduler and type(make_scheduler("DDIM_Cog", None)) is CogVideoXDDIMScheduler
+    d = tmp_path / "scheduler"
+    d.mkdir()
+    (d / "scheduler_config.json").write_text(json.dumps({"_class_name": "CogVideoXDDIMScheduler", "snr_shift_scale": 3.0,
+                                                         "clip_sample_range": 1.0, "sample_max_value": 1.0, "trained_betas": None}))
+    assert make_scheduler("DDIM_Cog", str(tmp_path)).config.snr_shift_scale == 3.0
+    for name in ("Euler", "Euler A", "DPM++", "PNDM"):
+        with pytest.raises(NotImplementedError, match="not built"):
+            make_scheduler(name, None)
+    with pytest.raises(ValueError, match="unknown sampler"):
+        make_scheduler("LCM", None)
+
+    class _Foreign:
+        init_noise_sigma = 1.0
+    with pytest.raises(NotImplementedError, match="DDIM_Cog"):
+        TrajCrafter_Pipeline(None, None, None, None, _Foreign())
+
+
+def test_run_cli_parses_the_reference_options():
+    from trajectorycrafter_amd.run import parse
+    a = parse(["generate", "--model-dir", "ckpt", "--conditioning", "c.safetensors", "--out", "o.safetensors", "--sampler", "DDIM_Cog",
+               "--steps", "30", "--seed", "7"])
+    assert (a.cmd, a.sampler, a.steps, a.seed, a.transformer_dir, a.guidance_scale) == ("generate", "DDIM_Cog", 30, 7, None, None)
+    o = parse(["orbits", "--model-dir", "ckpt", "--clip", "clip.safetensors", "--out", "o.safetensors", "--variants", "left_-30,right_90",
+               "--radius", "0.5"])
+    assert (o.cmd, o.variants, o.radius, o.no_mask) == ("orbits", "left_-30,right_90", 0.5, False)
+    with pytest.raises(SystemExit):
+        parse(["generate", "--out", "o"])
+
+
 @pytest.mark.parametrize("hw", [(480, 720), (384, 672), (256, 256)])
 def test_rope_tables_match_oracle(hw):
     H, W = hw

@@ -339,6 +339,26 @@ def test_cfg_ddim_step_matches_oracle(ops, t):
     assert_bf16_close(got, s.step(Prec("bf16"), bf(u).float(), t, x), atol=1e-5)
 
 
+@pytest.mark.parametrize("t", [999, 499, 19])
+def test_cfg_ddim_cog_step_matches_oracle(ops, t):
+    """`tcx_cfg_ddim_cog_step` (sampler "DDIM_Cog") vs the oracle's CogVideoXDDIMScheduler.step under the bf16 contract, through
+    the product scheduler's `fused_cfg_step`."""
+    from trajectorycrafter_amd.scheduler import CogVideoXDDIMScheduler
+    g = torch.Generator().manual_seed(100 + t)
+    s, ps = dr.CogVideoXDDIMScheduler(), CogVideoXDDIMScheduler()
+    s.set_timesteps(50), ps.set_timesteps(50)
+    x = bf(torch.randn(1, 13, 16, 12, 18, generator=g))
+    pred = torch.randn(2, 13, 16, 12, 18, generator=g)
+    u, c = pred.chunk(2)
+    ref = s.step(Prec("bf16"), u + 6.0 * (c - u), t, x)
+    d = dev(pred)
+    got = ps.fused_cfg_step(d[:1], d[1:], dev(x), 6.0, t)
+    assert_bf16_close(got, ref, atol=1e-5)
+    got = ps.fused_cfg_step(dev(bf(u)), None, dev(x), 1.0, t)
+    assert_bf16_close(got, s.step(Prec("bf16"), bf(u).float(), t, x), atol=1e-5)
+    assert_bf16_close(ps.step(dev(bf(u)), t, dev(x))[0], s.step(Prec("bf16"), bf(u).float(), t, x), atol=1e-5)
+
+
 # ----------------------------------------------------------------------------- VAE kernels
 def to_cl(x):
     return x.permute(0, 2, 3, 4, 1).contiguous()

@@ -109,6 +109,43 @@ def test_ddim_bf16_promotion_quirk():
     torch.testing.assert_close(out, ap.sqrt() * x0 + (1 - ap).sqrt() * eps)
 
 
+def test_cog_ddim_is_the_same_ddim_update_on_a_shifted_schedule():
+    """`CogVideoXDDIMScheduler` ("DDIM_Cog"), known answers: (1) with snr_shift_scale = 1 its float64 schedule equals
+    DDIMScheduler's to fp32 precision (both are the zero-terminal-SNR rescale of the scaled-linear schedule; rescaling
+    alphas_cumprod directly or through the betas is the same map); (2) the SNR shift divides the SNR a/(1-a) by s exactly;
+    (3) its `a x + b x0` step is algebraically the DDIM update sqrt(a_prev) x0 + sqrt(1-a_prev) eps: equal in fp32 to 1e-5;
+    (4) first / last step limits."""
+    c, d = dr.CogVideoXDDIMScheduler(), dr.DDIMScheduler()
+    assert c.alphas_cumprod.dtype == torch.float64
+    torch.testing.assert_close(c.alphas_cumprod.float(), d.alphas_cumprod, rtol=2e-4, atol=1e-7)
+    assert abs(float(c.alphas_cumprod[-1])) < 1e-20 and abs(float(c.alphas_cumprod[0]) - (1 - 0.00085)) < 1e-9
+    raw = torch.cumprod(1 - torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float64) ** 2, 0)
+    sh = dr.CogVideoXDDIMScheduler(snr_shift_scale=3.0, rescale_betas_zero_snr=False).alphas_cumprod
+    torch.testing.assert_close(sh / (1 - sh), raw / (1 - raw) / 3.0, rtol=1e-12, atol=0)
+    c.set_timesteps(50), d.set_timesteps(50)
+    assert c.timesteps.tolist() == d.timesteps.tolist()
+    x, v = torch.randn(1, 2, 3), torch.randn(1, 2, 3)
+    for t in (999, 979, 499, 19):
+        torch.testing.assert_close(c.step(P, v, t, x), d.step(P, v, t, x), rtol=2e-4, atol=2e-5)
+    a_prev = c.alphas_cumprod[979]
+    torch.testing.assert_close(c.step(P, v, 999, x), (a_prev.sqrt() * (-v) + (1 - a_prev).sqrt() * x).float(), rtol=1e-5, atol=1e-6)
+    a = c.alphas_cumprod[19]
+    torch.testing.assert_close(c.step(P, v, 19, x), (a.sqrt() * x - (1 - a).sqrt() * v).float(), rtol=1e-5, atol=1e-6)
+
+
+def test_cog_ddim_bf16_rounding_points():
+    c = dr.CogVideoXDDIMScheduler()
+    c.set_timesteps(50)
+    x = torch.randn(64).to(torch.bfloat16)
+    v = torch.randn(64)
+    a_t, a_prev = c.coeffs(499)
+    sa, sb = float(a_t ** 0.5), float((1 - a_t) ** 0.5)
+    ca = float(((1 - a_prev) / (1 - a_t)) ** 0.5)
+    cb = float(a_prev ** 0.5 - a_t ** 0.5 * ((1 - a_prev) / (1 - a_t)) ** 0.5)
+    x0 = (sa * x.float()).bfloat16().float() - sb * v
+    torch.testing.assert_close(c.step(Prec("bf16"), v, 499, x), (ca * x.float()).bfloat16().float() + cb * x0)
+
+
 def test_upsample3d_frame_rules():
     x = torch.arange(3.)[None, None, :, None, None].expand(1, 1, 3, 2, 2)
     y = dr.upsample3d_nearest(x, True)                 # odd T: frame0 spatial only, rest x2 in time

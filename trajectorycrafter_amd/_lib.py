@@ -35,6 +35,7 @@ SIGNATURES = {
     "tcx_patchify": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "tcx_unpatchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "tcx_cfg_ddim_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _vp],
+    "tcx_cfg_ddim_cog_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp],
     "tcx_conv3d_cl": [_vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 16 + [_vp, _vp],
     "tcx_conv3d_route": [_i32] * 14,
     "tcx_avgpool_t": [_vp, _vp, _i32, _i32, _i64, _i32, _vp],

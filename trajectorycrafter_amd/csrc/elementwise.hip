@@ -192,6 +192,27 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const void* u, const void
     }
 }
 
+// CogVideoXDDIMScheduler.step (sampler "DDIM_Cog"): x0 = bf16r(sa x) - sb noise;  prev = bf16r(ca x) + cb x0
+template <bool PRED_F32>
+__global__ __launch_bounds__(256) void cfg_ddim_cog_kernel(const void* u, const void* c, const uint16_t* x, uint16_t* out,
+                                                           int64_t n, float g, float sa, float sb, float ca, float cb) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float uu, cc = 0.f;
+        if constexpr (PRED_F32) {
+            uu = reinterpret_cast<const float*>(u)[i];
+            if (c) cc = reinterpret_cast<const float*>(c)[i];
+        } else {
+            uu = bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(u)[i]);
+            if (c) cc = bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(c)[i]);
+        }
+        const float noise = c ? uu + g * (cc - uu) : uu;
+        const float xs = bf16_bits_to_f32(x[i]);
+        const float x0 = round_bf16(sa * xs) - sb * noise;      // 0-dim fp64 scalar * bf16 tensor stays bf16 (same promotion quirk)
+        const float prev = round_bf16(ca * xs) + cb * x0;
+        out[i] = (uint16_t)(pack_bf16(prev, 0.f) & 0xffff);
+    }
+}
+
 // [N, C, S] (S = T*H*W) bf16 -> channels-last [N, S, C] bf16, scaled by `mul`; LDS-tiled transpose
 __global__ __launch_bounds__(256) void ncthw_to_cl_kernel(const uint16_t* x, uint16_t* y, int32_t C, int64_t S, float mul) {
     __shared__ uint16_t tile[32][33];
@@ -366,6 +387,21 @@ extern "C" int tcx_cfg_ddim_step(const void* u, const void* c, const void* x, vo
         hipLaunchKernelGGL(cfg_ddim_kernel<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, sa, sb, sap, sbp);
     else
         hipLaunchKernelGGL(cfg_ddim_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, sa, sb, sap, sbp);
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_cfg_ddim_cog_step(const void* u, const void* c, const void* x, void* out, int64_t n, float guidance,
+                                     float sqrt_alpha_t, float sqrt_beta_t, float coef_sample, float coef_x0, int32_t pred_dtype,
+                                     void* stream) {
+    TCX_CHECK(u && x && out, TCX_E_NULL, "tcx_cfg_ddim_cog_step: null pointer");
+    TCX_CHECK(n > 0, TCX_E_SHAPE, "tcx_cfg_ddim_cog_step: n must be positive");
+    TCX_CHECK(pred_dtype == TCX_BF16 || pred_dtype == TCX_F32, TCX_E_DTYPE, "tcx_cfg_ddim_cog_step: bad pred_dtype %d", pred_dtype);
+    TCX_CHECK(sqrt_alpha_t >= 0.f && sqrt_alpha_t <= 1.f && sqrt_beta_t >= 0.f && sqrt_beta_t <= 1.f, TCX_E_SHAPE,
+              "tcx_cfg_ddim_cog_step: sqrt(alpha_t), sqrt(1 - alpha_t) must be in [0,1]");
+    if (pred_dtype == TCX_F32)
+        hipLaunchKernelGGL(cfg_ddim_cog_kernel<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, sqrt_alpha_t, sqrt_beta_t, coef_sample, coef_x0);
+    else
+        hipLaunchKernelGGL(cfg_ddim_cog_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, sqrt_alpha_t, sqrt_beta_t, coef_sample, coef_x0);
     TCX_LAUNCH_RET();
 }
 

@@ -123,6 +123,10 @@ class TrajCrafter_Pipeline:
         self.tokenizer, self.text_encoder = tokenizer, text_encoder
         self.vae, self.transformer = vae, transformer
         self.scheduler = scheduler if scheduler is not None else DDIMScheduler()
+        if not hasattr(self.scheduler, "fused_cfg_step"):
+            raise NotImplementedError(
+                f"scheduler {type(self.scheduler).__name__} is not built on this path: the denoise loop fuses CFG + step into one "
+                "kernel per scheduler class; built: scheduler.DDIMScheduler ('DDIM_Origin'), scheduler.CogVideoXDDIMScheduler ('DDIM_Cog')")
         self.vae_scale_factor_spatial = 2 ** (len(self.vae.config.block_out_channels) - 1) if vae is not None else 8
         self.vae_scale_factor_temporal = int(self.vae.config.temporal_compression_ratio) if vae is not None else 4
         self.vae_scale_factor = self.vae_scale_factor_spatial
@@ -390,6 +394,10 @@ class TrajCrafter_Pipeline:
 
         if output_type == "latent":
             video_out = st.latents
+        elif output_type == "cl_bf16":
+            # the decoder's own bf16 output, channels-last [B,F,H,W,3], before the frame conversion of decode_latents: what the
+            # data-parallel runner all-gathers (driver.run_orbits); `vae.cl_to_frames` of it == decode_latents, bit for bit
+            video_out = self.vae.decode_cl_bf16(st.latents.permute(0, 2, 1, 3, 4), scale=1.0 / self.vae.config.scaling_factor)
         else:
             video_out = self.decode_latents(st.latents)
         ev2.record()
@@ -485,12 +493,11 @@ class TrajCrafter_Pipeline:
         if st.use_dynamic_cfg:                                                     # :1142-1156
             n = st.num_inference_steps
             self._guidance_scale = 1 + st.guidance_scale * ((1 - math.cos(math.pi * ((n - t) / n) ** 5.0)) / 2)
-        a_t, a_prev = self.scheduler.coeffs(t)
-        if st.do_cfg:                                                              # :1157-1178 fused
+        if st.do_cfg:                                                              # :1157-1178 fused, per scheduler class
             u, c = noise_pred[:st.batch_size], noise_pred[st.batch_size:]
-            st.latents = ops.cfg_ddim_step(u, c, st.latents, self.guidance_scale, a_t, a_prev)
+            st.latents = self.scheduler.fused_cfg_step(u, c, st.latents, self.guidance_scale, t)
         else:
-            st.latents = ops.cfg_ddim_step(noise_pred, None, st.latents, 1.0, a_t, a_prev)
+            st.latents = self.scheduler.fused_cfg_step(noise_pred, None, st.latents, 1.0, t)
         return st.latents
 
     def timings(self) -> Dict[str, float]:

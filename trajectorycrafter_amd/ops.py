@@ -256,6 +256,23 @@ def cfg_ddim_step(uncond: torch.Tensor, cond: Optional[torch.Tensor], x: torch.T
     return out
 
 
+def cfg_ddim_cog_step(uncond: torch.Tensor, cond: Optional[torch.Tensor], x: torch.Tensor, guidance: float, sqrt_alpha_t: float,
+                      sqrt_beta_t: float, coef_sample: float, coef_x0: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """CFG + `CogVideoXDDIMScheduler.step` (sampler "DDIM_Cog"), fused; coefficients from the scheduler's float64 tables."""
+    _need(x, "x")
+    if uncond.dtype not in (BF16, torch.float32):
+        raise TcxError(f"cfg_ddim_cog_step: prediction dtype {uncond.dtype} unsupported")
+    if not (uncond.is_contiguous() and x.is_contiguous() and (cond is None or cond.is_contiguous())):
+        raise TcxError("cfg_ddim_cog_step: tensors must be contiguous")
+    if uncond.numel() != x.numel() or (cond is not None and (cond.numel() != x.numel() or cond.dtype != uncond.dtype)):
+        raise TcxError("cfg_ddim_cog_step: size / dtype mismatch")
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.load().tcx_cfg_ddim_cog_step(_p(uncond), _p(cond), _p(x), _p(out), x.numel(), float(guidance), float(sqrt_alpha_t),
+                                            float(sqrt_beta_t), float(coef_sample), float(coef_x0),
+                                            TCX_F32 if uncond.dtype == torch.float32 else TCX_BF16, _stream()), "tcx_cfg_ddim_cog_step")
+    return out
+
+
 # ----------------------------------------------------------------------------- VAE (channels-last [N,T,H,W,C])
 def conv3d_cl(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], cache: Optional[torch.Tensor] = None,
               res: Optional[torch.Tensor] = None, ups: int = 0, t_map: Optional[torch.Tensor] = None,

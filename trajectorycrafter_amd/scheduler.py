@@ -83,12 +83,55 @@ class DDIMScheduler:
         a_prev = float(self.alphas_cumprod[prev]) if prev >= 0 else float(self.final_alpha_cumprod)
         return a_t, a_prev
 
+    def fused_cfg_step(self, uncond: torch.Tensor, cond: Optional[torch.Tensor], sample: torch.Tensor, guidance: float,
+                       timestep: int) -> torch.Tensor:
+        """CFG combine (pipeline :1157-1161) + `step` + the bf16 cast (:1178) as ONE kernel (`tcx_cfg_ddim_step`)."""
+        from . import ops
+        a_t, a_prev = self.coeffs(int(timestep))
+        return ops.cfg_ddim_step(uncond, cond, sample, guidance, a_t, a_prev)
+
     def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, eta: float = 0.0,
              generator=None, return_dict: bool = False):
         """diffusers-shaped step (no guidance): prev_sample = DDIM(model_output, sample), bf16 on the GPU."""
-        from . import ops
         if eta != 0.0:
             raise ValueError("only eta = 0 (deterministic DDIM) is implemented")
+        return (self.fused_cfg_step(model_output.contiguous(), None, sample.contiguous(), 1.0, int(timestep)),)
+
+
+class CogVideoXDDIMScheduler(DDIMScheduler):
+    """diffusers `CogVideoXDDIMScheduler` — the reference's "DDIM_Cog" sampler (demo.py:652).  Same timestep grid and the
+    same DDIM (eta = 0) update as `DDIMScheduler`, with three differences, all kept: the noise schedule is held in float64
+    and SNR-shifted (`alphas_cumprod / (s + (1 - s) alphas_cumprod)`, s = `snr_shift_scale`) BEFORE the zero-terminal-SNR rescale,
+    which is applied to alphas_cumprod directly; and `step` is written in the `a_t x + b_t x0` form, whose bf16 rounding points
+    differ from the `sqrt(a_prev) x0 + sqrt(1 - a_prev) eps` form (`tcx_cfg_ddim_cog_step`).  Defaults: the class defaults of
+    diffusers except the values CogVideoX-5b's scheduler_config.json overrides (as recalled, SURVEY §8c: v_prediction,
+    trailing, zero-SNR, snr_shift_scale 1.0 for the 5B family — 3.0, the class default, is the 2B value)."""
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
+                 beta_schedule: str = "scaled_linear", prediction_type: str = "v_prediction",
+                 timestep_spacing: str = "trailing", rescale_betas_zero_snr: bool = True, set_alpha_to_one: bool = True,
+                 steps_offset: int = 0, clip_sample: bool = False, snr_shift_scale: float = 1.0, **unused):
+        super().__init__(num_train_timesteps, beta_start, beta_end, beta_schedule, prediction_type, timestep_spacing,
+                         rescale_betas_zero_snr, set_alpha_to_one, steps_offset, clip_sample)
+        self.config = FrozenConfig(dict(self.config), snr_shift_scale=snr_shift_scale)
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float64) ** 2
+        abar = torch.cumprod(1.0 - betas, dim=0)
+        abar = abar / (snr_shift_scale + (1 - snr_shift_scale) * abar)                    # SNR shift (SD3-style)
+        if rescale_betas_zero_snr:
+            r = abar.sqrt()
+            r0, rT = r[0].clone(), r[-1].clone()
+            abar = ((r - rT) * (r0 / (r0 - rT))) ** 2
+        self.betas = betas
+        self.alphas_cumprod = abar                                                       # float64
+        self.final_alpha_cumprod = torch.tensor(1.0, dtype=torch.float64) if set_alpha_to_one else abar[0]
+
+    def step_coeffs(self, timestep: int):
+        """(sqrt(a_t), sqrt(1 - a_t), coef_sample, coef_x0) in float64 arithmetic, as python floats."""
         a_t, a_prev = self.coeffs(int(timestep))
-        prev = ops.cfg_ddim_step(model_output.contiguous(), None, sample.contiguous(), 1.0, a_t, a_prev)
-        return (prev,)
+        ca = ((1 - a_prev) / (1 - a_t)) ** 0.5
+        return a_t ** 0.5, (1 - a_t) ** 0.5, ca, a_prev ** 0.5 - a_t ** 0.5 * ca
+
+    def fused_cfg_step(self, uncond, cond, sample, guidance: float, timestep: int) -> torch.Tensor:
+        from . import ops
+        sa, sb, ca, cb = self.step_coeffs(timestep)
+        return ops.cfg_ddim_cog_step(uncond, cond, sample, guidance, sa, sb, ca, cb)
