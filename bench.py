@@ -43,7 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md; 2:1-sparsity figures never used)
-CPU_BASELINE_BUDGET_S = 30.0
+CPU_BASELINE_BUDGET_S = 90.0       # hard limit for the child (its sample is sized for ~20 s on 16 cores)
 
 
 def parse(argv=None):
@@ -58,6 +58,7 @@ def parse(argv=None):
     ap.add_argument("--layers", type=int, default=42, help="(debug) fewer layers => NOT the benchmark config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="(debug) skip the VAE decode => NOT the benchmark config")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(child of the bench) time the oracle sample on the CPU, print its JSON")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="(CPU test hook) run only the launcher + rank plumbing on gloo, no GPU, no model")
     return ap.parse_args(argv)
@@ -122,15 +123,31 @@ def make_inputs(args, device, seed):
 
 
 # ------------------------------------------------------------------------------------------- CPU baseline (oracle)
-def cpu_baseline(args, threads: int = 16, attn_heads: int = 2, cross_heads: int = 1):
-    """Oracle (CPU port of the reference, fp32) on the host cores, bounded to ~10-20 s: at the full 480x720 token count,
-    B=1, time (a) every row-wise / GEMM piece of ONE CogVideoXBlock, (b) its joint attention on `attn_heads` of the 48
-    heads, (c) the GEMMs + LayerNorms of ONE PerceiverCrossAttention and (d) its attention on `cross_heads` of the 16
-    heads; heads are independent, so (b) and (d) scale linearly.  A clip is extrapolated as 2*steps forwards x (42 blocks +
-    21 cross layers).  Reported baseline, not the target."""
+def _median_time(fn, reps: int):
+    ts = []
+    out = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2], out
+
+
+def cpu_baseline(args, threads: int = 16, reps: int = 3, row_tokens: int = 2048, vae_crop=(15, 23)):
+    """Oracle (CPU restatement of the reference, fp32) on the host cores, bounded to ~20 s, every piece `reps` times (median):
+      (a) the row-wise / GEMM part of ONE CogVideoXBlock (2 x LayerNormZero, qkv + out projections, q/k LayerNorm + RoPE, FFN,
+          gated residuals) on `row_tokens` of the S = 17 776 tokens — every one of these ops is linear in the token count;
+      (b) its joint attention on ONE of the 48 heads at the FULL token count (quadratic in S, so never subsampled; heads are
+          independent and scale linearly);
+      (c) / (d) the same split for ONE PerceiverCrossAttention (1 of 16 heads);
+      (e) one 2-latent-frame chunk of the VAE decoder at default widths on a `vae_crop` latent window of the 60 x 90 grid (every
+          decoder op is linear in the pixel count), once.
+    A clip is extrapolated as 2 * steps forwards x (42 blocks + 21 cross layers) + 6.5 decode chunks.  Reported baseline, not
+    the target; the reference's own CPU path cannot run here (no `diffusers`, no weights)."""
     import torch
     from oracle import diffusers_restated as dr
     from oracle import transformer as otr
+    from oracle import vae as ovae
     from oracle.pipeline import prepare_rotary
     from oracle.prec import Prec
     from trajectorycrafter_amd import init_weights as iw
@@ -144,69 +161,85 @@ def cpu_baseline(args, threads: int = 16, attn_heads: int = 2, cross_heads: int 
     T = (args.frames - 1) // 4 + 1
     gh, gw = args.height // 16, args.width // 16
     Sv, S, Sr, D = T * gh * gw, T * gh * gw + 226, 3 * gh * gw, 3072
+    Ms = min(row_tokens, Sv)                                   # video tokens in the row sample (+ the 226 text tokens)
     g = torch.Generator().manual_seed(0)
     p = Prec("fp32")
-    x = torch.randn(1, S, D, generator=g)
-    temb, ref = torch.randn(1, 512, generator=g), torch.randn(1, Sr, D, generator=g)
+    x = torch.randn(1, 226 + Ms, D, generator=g)
+    temb, ref = torch.randn(1, 512, generator=g), torch.randn(1, min(Sr, Ms), D, generator=g)
     cos, sin = prepare_rotary(args.height, args.width, T, 2, 64)
-    pre = "transformer_blocks.0."
-    tick = time.perf_counter
-    # (a) block without attention: 2 x LayerNormZero, qkv + out projections, q/k LayerNorm + RoPE, FFN, gated residuals
-    t0 = tick()
-    n1, e1, gate, egate = dr.layer_norm_zero(p, sd, pre + "norm1.", x[:, 226:], x[:, :226], temb, 1e-5)
-    h = torch.cat([e1, n1], 1)
-    q, k, v = (p.linear(h, sd[pre + f"attn1.{n}.weight"], sd[pre + f"attn1.{n}.bias"]).view(1, S, 48, 64).transpose(1, 2)
-               for n in ("to_q", "to_k", "to_v"))
-    q = p.layer_norm(q, sd[pre + "attn1.norm_q.weight"], sd[pre + "attn1.norm_q.bias"], 1e-6)
-    k = p.layer_norm(k, sd[pre + "attn1.norm_k.weight"], sd[pre + "attn1.norm_k.bias"], 1e-6)
-    q = torch.cat([q[:, :, :226], dr.apply_rotary_emb(q[:, :, 226:], cos, sin)], 2)
-    k = torch.cat([k[:, :, :226], dr.apply_rotary_emb(k[:, :, 226:], cos, sin)], 2)
-    o = p.linear(v.transpose(1, 2).reshape(1, S, D), sd[pre + "attn1.to_out.0.weight"], sd[pre + "attn1.to_out.0.bias"])
-    x2 = x + torch.cat([egate.expand(1, 226, D), gate.expand(1, Sv, D)], 1) * o
-    n2, e2, gate, egate = dr.layer_norm_zero(p, sd, pre + "norm2.", x2[:, 226:], x2[:, :226], temb, 1e-5)
-    ff = dr.feed_forward(p, sd, pre + "ff.", torch.cat([e2, n2], 1))
-    x3 = x2 + torch.cat([egate.expand(1, 226, D), gate.expand(1, Sv, D)], 1) * ff
-    t_rows = tick() - t0
-    # (b) joint attention, `attn_heads` heads
-    t0 = tick()
-    dr.sdpa(p, q[:, :attn_heads], k[:, :attn_heads], v[:, :attn_heads], 0.125)
-    t_attn = (tick() - t0) * 48 / attn_heads
-    # (c) cross layer without attention
-    cp = "perceiver_cross_attention.0."
-    t0 = tick()
-    xn = p.layer_norm(ref, sd[cp + "norm1.weight"], sd[cp + "norm1.bias"], 1e-5)
-    ln = p.layer_norm(x3[:, 226:], sd[cp + "norm2.weight"], sd[cp + "norm2.bias"], 1e-5)
-    cq = p.linear(ln, sd[cp + "to_q.weight"]).view(1, Sv, 16, 128).transpose(1, 2) * 128 ** -0.25
-    ck, cv = (t.view(1, Sr, 16, 128).transpose(1, 2) for t in p.linear(xn, sd[cp + "to_kv.weight"]).chunk(2, -1))
-    ck = ck * 128 ** -0.25
-    p.linear(cq.transpose(1, 2).reshape(1, Sv, 2048), sd[cp + "to_out.weight"])
-    t_crows = tick() - t0
-    # (d) cross attention, `cross_heads` heads
-    t0 = tick()
-    dr.sdpa(p, cq[:, :cross_heads], ck[:, :cross_heads], cv[:, :cross_heads], 1.0)
-    t_cattn = (tick() - t0) * 16 / cross_heads
+    pre, cp = "transformer_blocks.0.", "perceiver_cross_attention.0."
+
+    def rows():                                                # (a)
+        n1, e1, gate, egate = dr.layer_norm_zero(p, sd, pre + "norm1.", x[:, 226:], x[:, :226], temb, 1e-5)
+        h = torch.cat([e1, n1], 1)
+        q, k, v = (p.linear(h, sd[pre + f"attn1.{n}.weight"], sd[pre + f"attn1.{n}.bias"]).view(1, 226 + Ms, 48, 64).transpose(1, 2)
+                   for n in ("to_q", "to_k", "to_v"))
+        q = p.layer_norm(q, sd[pre + "attn1.norm_q.weight"], sd[pre + "attn1.norm_q.bias"], 1e-6)
+        k = p.layer_norm(k, sd[pre + "attn1.norm_k.weight"], sd[pre + "attn1.norm_k.bias"], 1e-6)
+        q = torch.cat([q[:, :, :226], dr.apply_rotary_emb(q[:, :, 226:], cos[:Ms], sin[:Ms])], 2)
+        k = torch.cat([k[:, :, :226], dr.apply_rotary_emb(k[:, :, 226:], cos[:Ms], sin[:Ms])], 2)
+        o = p.linear(v.transpose(1, 2).reshape(1, 226 + Ms, D), sd[pre + "attn1.to_out.0.weight"], sd[pre + "attn1.to_out.0.bias"])
+        x2 = x + torch.cat([egate.expand(1, 226, D), gate.expand(1, Ms, D)], 1) * o
+        n2, e2, gate, egate = dr.layer_norm_zero(p, sd, pre + "norm2.", x2[:, 226:], x2[:, :226], temb, 1e-5)
+        ff = dr.feed_forward(p, sd, pre + "ff.", torch.cat([e2, n2], 1))
+        return x2 + torch.cat([egate.expand(1, 226, D), gate.expand(1, Ms, D)], 1) * ff
+
+    t_rows, x3 = _median_time(rows, reps)
+    t_rows *= S / (226 + Ms)
+    qh, kh, vh = (torch.randn(1, 1, S, 64, generator=g) for _ in range(3))
+    t_attn = _median_time(lambda: dr.sdpa(p, qh, kh, vh, 0.125), reps)[0] * 48                     # (b)
+
+    def crows():                                               # (c)
+        xn = p.layer_norm(ref, sd[cp + "norm1.weight"], sd[cp + "norm1.bias"], 1e-5)
+        ln = p.layer_norm(x3[:, 226:], sd[cp + "norm2.weight"], sd[cp + "norm2.bias"], 1e-5)
+        cq = p.linear(ln, sd[cp + "to_q.weight"]) * 128 ** -0.25
+        ckv = p.linear(xn, sd[cp + "to_kv.weight"])
+        return p.linear(cq, sd[cp + "to_out.weight"]), ckv
+
+    # the q / out projections scale with Sv, the kv projection with Sr: both sampled at Ms rows
+    t_crows = _median_time(crows, reps)[0] * (Sv / Ms)
+    cq, ck, cv = torch.randn(1, 1, Sv, 128, generator=g), torch.randn(1, 1, Sr, 128, generator=g), torch.randn(1, 1, Sr, 128, generator=g)
+    t_cattn = _median_time(lambda: dr.sdpa(p, cq, ck, cv, 1.0), reps)[0] * 16                      # (d)
+
+    # (e) VAE decoder, default widths, one 2-latent-frame chunk on a crop of the latent grid
+    vcfg = dict(ovae.DEFAULT_CONFIG)
+    vsd = iw.random_state_dict(iw.vae_param_shapes(vcfg, decoder=True, encoder=False), seed=1)
+    ch, cw = min(vae_crop[0], args.height // 8), min(vae_crop[1], args.width // 8)
+    z = torch.randn(1, 16, 2, ch, cw, generator=g)
+    t0 = time.perf_counter()
+    ovae.decoder_forward(p, vsd, vcfg, z, {})
+    t_chunk = (time.perf_counter() - t0) * ((args.height // 8) * (args.width // 8)) / (ch * cw)
+    n_chunks = T / 2.0
     t_block, t_cross = t_rows + t_attn, t_crows + t_cattn
-    clip_s = 2 * args.denoise_steps * (42 * t_block + 21 * t_cross)
+    denoise_s = 2 * args.denoise_steps * (42 * t_block + 21 * t_cross)
+    clip_s = denoise_s + n_chunks * t_chunk
     return {"value": 1.0 / clip_s, "unit": "video-latents/s", "cores": threads, "kind": "port",
-            "sample": f"oracle fp32, {args.frames}f {args.height}x{args.width} (S={S}), B=1: CogVideoXBlock = rows/GEMMs {t_rows:.2f} s + "
-                      f"attention {t_attn:.2f} s ({attn_heads}/48 heads timed, x{48 // attn_heads}); PerceiverCrossAttention = rows/GEMMs "
-                      f"{t_crows:.2f} s + attention {t_cattn:.2f} s ({cross_heads}/16 heads timed); clip extrapolated as "
-                      f"{2 * args.denoise_steps} forwards x (42 blocks + 21 cross layers); embeds and VAE decode excluded",
-            "extrapolated_clip_seconds": clip_s}
+            "sample": f"oracle fp32 on {threads} threads, {args.frames}f {args.height}x{args.width} (S={S}), B=1, median of {reps}: CogVideoXBlock = "
+                      f"rows/GEMMs {t_rows:.2f} s ({226 + Ms} of {S} tokens timed, linear) + attention {t_attn:.2f} s (1/48 heads timed at full S); "
+                      f"PerceiverCrossAttention = rows/GEMMs {t_crows:.2f} s + attention {t_cattn:.2f} s (1/16 heads); VAE decode chunk "
+                      f"{t_chunk:.1f} s ({ch}x{cw} of the {args.height // 8}x{args.width // 8} latent grid timed once, linear); clip extrapolated as "
+                      f"{2 * args.denoise_steps} forwards x (42 blocks + 21 cross layers) + {n_chunks:.1f} decode chunks; patch / time embeds excluded",
+            "extrapolated_clip_seconds": clip_s, "extrapolated_denoise_seconds": denoise_s, "extrapolated_decode_seconds": n_chunks * t_chunk}
 
 
 def cpu_baseline_bounded(args):
-    """Run `cpu_baseline` on a worker thread; after CPU_BASELINE_BUDGET_S give up so that the JSON line is always printed."""
-    import concurrent.futures as cf
-    ex = cf.ThreadPoolExecutor(max_workers=1)
-    fut = ex.submit(cpu_baseline, args)
+    """`cpu_baseline` in a CHILD process (`bench.py --cpu-baseline-only`, CPU only, never touches the GPU) with a hard time
+    limit: a slow host cannot hold back the JSON line, nothing is left running at exit, and this process leaves through the
+    normal interpreter shutdown (so a profiler attached to it still writes its output)."""
+    skipped = lambda why: {"value": None, "unit": "video-latents/s", "cores": None, "kind": "port", "sample": f"skipped: {why}"}
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--frames", str(args.frames), "--height", str(args.height),
+           "--width", str(args.width), "--denoise-steps", str(args.denoise_steps)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")     # the child is a CPU program
     try:
-        return fut.result(timeout=CPU_BASELINE_BUDGET_S), False
-    except cf.TimeoutError:
-        return {"value": None, "unit": "video-latents/s", "cores": None, "kind": "port",
-                "sample": f"skipped: the oracle sample did not finish within {CPU_BASELINE_BUDGET_S:.0f} s on this host"}, True
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=CPU_BASELINE_BUDGET_S)
+    except subprocess.TimeoutExpired:
+        return skipped(f"the oracle sample did not finish within {CPU_BASELINE_BUDGET_S:.0f} s on this host")
+    if r.returncode != 0:
+        return skipped(f"child exited {r.returncode}: {r.stderr.strip()[-300:]}")
+    try:
+        return json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:                                       # the baseline is a reported extra: never lose the bench line
-        return {"value": None, "unit": "video-latents/s", "cores": None, "kind": "port", "sample": f"skipped: {type(e).__name__}: {e}"}, False
+        return skipped(f"{type(e).__name__}: {e}")
 
 
 # ------------------------------------------------------------------------------------------- rank plumbing
@@ -251,18 +284,20 @@ def run_rank(args):
     import torch.distributed as dist
     from trajectorycrafter_amd import dp, ops
 
+    # RCCL ("nccl") is THE collective backend of the path.  gloo (host-mediated) is only ever used when asked for explicitly
+    # (TCX_DIST_BACKEND=gloo: the one-card rehearsal); an RCCL failure is fatal, with its error text — never a silent fallback
+    # that would put a host-staged gather into a scaling number.
     backend = os.environ.get("TCX_DIST_BACKEND", "nccl")
     if world > 1:
         try:
             dp.init_distributed(backend)
-        except Exception as e:                                  # RCCL unavailable on this node: the one gather of the path can
-            if backend != "nccl":                               # also go through gloo (host-mediated, ~0.2 s per clip); say so
-                raise
-            print(f"[bench] rank {rank}: RCCL init failed ({type(e).__name__}: {e}); falling back to gloo", file=sys.stderr, flush=True)
-            if dist.is_initialized():
-                dist.destroy_process_group()
-            backend = "gloo"
-            dp.init_distributed(backend)
+        except Exception as e:
+            print(f"[bench] rank {rank}: init_process_group(backend={backend!r}) FAILED: {type(e).__name__}: {e}\n"
+                  f"[bench] no fallback is taken (set TCX_DIST_BACKEND=gloo explicitly for a host-mediated rehearsal)", file=sys.stderr, flush=True)
+            raise SystemExit(3)
+        if backend != "nccl":
+            print(f"[bench] WARNING: collective backend is {backend!r}, not RCCL: the all-gather is host-mediated; this is a rehearsal, "
+                  "not a scaling measurement", file=sys.stderr, flush=True)
     t_init = time.perf_counter()
     pipe = build_models(args, device)
     inp = make_inputs(args, device, seed=43 + rank)            # one independent trajectory per rank (seeds 43..50)
@@ -368,13 +403,14 @@ def run_rank(args):
                          "launches": sa["n"], "avg_launch_ms": avg_ms,
                          "algorithmic_flop_per_launch": flop_per_launch},
         }
-        hung = False
+        dbg = {k: os.environ[k] for k in ("TCX_CONV_GENERIC", "TCX_LIB", "TCX_DIST_BACKEND", "TCX_BENCH_SINGLE_DEVICE") if os.environ.get(k)}
+        if dbg:                                                 # switches that change what runs: never unrecorded
+            rec["config"]["debug_env"] = dbg
+        if world > 1 and backend != "nccl":
+            rec["collective_backend_warning"] = f"{backend}: host-mediated all-gather, NOT RCCL — rehearsal only"
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"], hung = cpu_baseline_bounded(args)
+            rec["cpu_baseline"] = cpu_baseline_bounded(args)
         print(json.dumps(rec), flush=True)
-        if hung:                                                # the oracle thread is still running: leave without joining it
-            sys.stdout.flush()
-            os._exit(0)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -383,6 +419,9 @@ def run_rank(args):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
+    if args.cpu_baseline_only:                                  # child process of cpu_baseline_bounded: CPU only
+        print(json.dumps(cpu_baseline(args)), flush=True)
+        return
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args, argv))                     # no torch.cuda / HIP call has happened in this process
     run_rank(args)

@@ -57,6 +57,50 @@ def vae_default(gpu):
     return vae, cfg, sdf
 
 
+def _tap_conv(x, w, b=None, stride=1, padding=0):
+    """N-d convolution as a sum over the kernel taps of channel matmuls in fp32 (`y += x[.., tap window, :] @ w[:, :, tap]^T`):
+    the same arithmetic as F.conv2d / F.conv3d up to fp32 summation order.  Only here because MIOpen's fp32 conv3d takes minutes
+    per layer at 128 x 9 x 480 x 720; torch matmul is the checker's engine instead (validated against F.conv3d below)."""
+    nd = x.dim() - 2
+    st = (stride,) * nd if isinstance(stride, int) else tuple(stride)
+    pd = (padding,) * nd if isinstance(padding, int) else tuple(padding)
+    if any(pd):
+        x = torch.nn.functional.pad(x, [v for q in reversed(pd) for v in (q, q)])
+    xl = x.movedim(1, -1)                                              # [B, *spatial, C]
+    ks = w.shape[2:]
+    out_sp = [(xl.shape[1 + i] - ks[i]) // st[i] + 1 for i in range(nd)]
+    y = None
+    import itertools
+    for tap in itertools.product(*[range(k) for k in ks]):
+        idx = (slice(None),) + tuple(slice(tap[i], tap[i] + (out_sp[i] - 1) * st[i] + 1, st[i]) for i in range(nd))
+        wt = w[(slice(None), slice(None)) + tap]                       # [O, C]
+        t = torch.matmul(xl[idx], wt.t())
+        y = t if y is None else y.add_(t)
+    if b is not None:
+        y = y + b
+    return y.movedim(-1, 1).contiguous()
+
+
+@pytest.fixture()
+def fast_oracle_convs(monkeypatch, gpu):
+    """Route the oracle's F.conv2d / F.conv3d through `_tap_conv` for the duration of a full-size test, after checking it
+    against the real F.conv3d / F.conv2d on the device at small sizes (stride, padding, 1x1x1 and 3x3x3 kernels)."""
+    import torch.nn.functional as F
+    g = torch.Generator(device=gpu).manual_seed(1)
+    x3 = torch.randn(2, 24, 5, 14, 18, device=gpu, generator=g)
+    for k in ((3, 3, 3), (1, 1, 1)):
+        w = torch.randn(40, 24, *k, device=gpu, generator=g) * 0.1
+        b = torch.randn(40, device=gpu, generator=g)
+        torch.testing.assert_close(_tap_conv(x3, w, b), F.conv3d(x3, w, b), rtol=1e-4, atol=1e-4)
+    x2 = torch.randn(3, 24, 15, 19, device=gpu, generator=g)
+    w2 = torch.randn(32, 24, 3, 3, device=gpu, generator=g) * 0.1
+    b2 = torch.randn(32, device=gpu, generator=g)
+    torch.testing.assert_close(_tap_conv(x2, w2, b2, stride=2, padding=0), F.conv2d(x2, w2, b2, stride=2, padding=0), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(_tap_conv(x2, w2, b2, stride=1, padding=1), F.conv2d(x2, w2, b2, stride=1, padding=1), rtol=1e-4, atol=1e-4)
+    monkeypatch.setattr(F, "conv3d", lambda x, w, b=None, stride=1, padding=0: _tap_conv(x, w, b, stride, padding))
+    monkeypatch.setattr(F, "conv2d", lambda x, w, b=None, stride=1, padding=0: _tap_conv(x, w, b, stride, padding))
+
+
 def _oracle_decode(sdf, cfg, z):
     with torch.no_grad():
         return (ovae.vae_decode(sdf, cfg, z.float(), prec="bf16").float(), ovae.vae_decode(sdf, cfg, z.float(), prec="fp32").float())
@@ -129,7 +173,7 @@ def test_default_width_encode_small_vs_oracle(vae_default, gpu):
     _check_deep(po.mean, co.mean, eo.mean, "default-width encode, 5 frames 72x88 (ragged tiles)")
 
 
-def test_fullsize_decode_first_two_chunks_vs_oracle(vae_default, gpu):
+def test_fullsize_decode_first_two_chunks_vs_oracle(vae_default, gpu, fast_oracle_convs):
     """480x720: latent frames 0..4 of the 13-frame clip = the first two decode chunks (3 + 2 latent frames -> 9 + 8 frames), every
     element of [1,3,17,480,720] against the oracle on the device."""
     vae, cfg, sdf = vae_default
@@ -145,7 +189,7 @@ def test_fullsize_decode_first_two_chunks_vs_oracle(vae_default, gpu):
     assert torch.equal(fr, (dec / 2 + 0.5).clamp(0, 1).float())
 
 
-def test_fullsize_encode_first_two_chunks_vs_oracle(vae_default, gpu):
+def test_fullsize_encode_first_two_chunks_vs_oracle(vae_default, gpu, fast_oracle_convs):
     """480x720: frames 0..8 = the first two encode chunks of the 49-frame clip (5 + 4 frames -> 2 + 1 latent frames), every
     element of the posterior moments [1,32,3,60,90]."""
     vae, cfg, sdf = vae_default

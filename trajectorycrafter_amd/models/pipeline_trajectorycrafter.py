@@ -305,7 +305,7 @@ class TrajCrafter_Pipeline:
         return y.reshape(b, f, c, height, width).permute(0, 2, 1, 3, 4)
 
     def _build_conditioning(self, video, mask_video, reference, height, width, do_cfg, dtype, device,
-                            noise_aug_strength: Optional[float] = 0.0563):
+                            noise_aug_strength: Optional[float] = 0.0563, masked_video_latents: Optional[torch.Tensor] = None):
         """reference :862-897 and :927-1028: pixels -> (inpaint_latents [B,T,17,h,w], ref_latents [B,Tr,16,h,w]) through
         the HIP VAE encoder.  The elementwise preparation (normalise, binarise, trilinear mask resize) is
         conditioning I/O on small tensors and stays in torch."""
@@ -326,7 +326,15 @@ class TrajCrafter_Pipeline:
         else:
             mask_cond = self._preprocess(mask_video.to(device), height, width, do_normalize=False, do_binarize=True)
             tile = mask_cond.repeat(1, 3, 1, 1, 1)
-            masked_video = init_video * (tile < 0.5) + torch.ones_like(init_video) * (tile > 0.5) * -1   # :969-974
+            if masked_video_latents is None:
+                masked_video = init_video * (tile < 0.5) + torch.ones_like(init_video) * (tile > 0.5) * -1   # :969-974
+            else:
+                # despite its name the reference treats this kwarg as a PIXEL-space masked video [B,3,F,H,W] in [-1,1] that
+                # replaces the one built from `video` and `mask_video`, and encodes it like that one (:975-989)
+                masked_video = masked_video_latents.to(device=device, dtype=torch.float32)
+                if masked_video.shape != init_video.shape:
+                    raise ValueError(f"`masked_video_latents` must be a pixel-space video {tuple(init_video.shape)} (the reference "
+                                     f"encodes it with the VAE, :975-989), got {tuple(masked_video.shape)}")
             if self.transformer.config.add_noise_in_inpaint_model:                                     # :488-491
                 masked_video = add_noise_to_reference_video(masked_video, ratio=noise_aug_strength)
             mv = (self.vae.encode(masked_video.to(dtype))[0].mode() * sf).to(dtype)                    # :498-502
@@ -374,7 +382,14 @@ class TrajCrafter_Pipeline:
             use_dynamic_cfg=use_dynamic_cfg, eta=eta, generator=generator, latents=latents, prompt_embeds=prompt_embeds,
             negative_prompt_embeds=negative_prompt_embeds, callback_on_step_end_tensor_inputs=callback_on_step_end_tensor_inputs,
             max_sequence_length=max_sequence_length, strength=strength, noise_aug_strength=noise_aug_strength,
-            inpaint_latents=inpaint_latents, ref_latents=ref_latents)
+            inpaint_latents=inpaint_latents, ref_latents=ref_latents, masked_video_latents=masked_video_latents)
+        # `timesteps=`: accepted and never read, exactly like the reference (declared :686, but :846 calls
+        # `scheduler.set_timesteps(num_inference_steps)` and `retrieve_timesteps` is never used).
+        pbar = None
+        if comfyui_progressbar:                                                      # :851-854 (ComfyUI node integration)
+            from comfy.utils import ProgressBar
+            pbar = ProgressBar(st.num_inference_steps + 2)
+            pbar.update(2)                                                           # :862, :925: conditioning + latents ready
 
         # 8. denoising loop (:1089-1198)
         ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
@@ -390,6 +405,8 @@ class TrajCrafter_Pipeline:
                 callback_outputs = callback_on_step_end(self, i, t, callback_kwargs)
                 st.latents = callback_outputs.pop("latents", st.latents)
                 st.prompt_embeds = callback_outputs.pop("prompt_embeds", st.prompt_embeds)
+            if pbar is not None:                                                     # :1197-1198
+                pbar.update(1)
         ev1.record()
 
         if output_type == "latent":
@@ -414,7 +431,8 @@ class TrajCrafter_Pipeline:
                         reference=None, num_frames=49, num_inference_steps=50, guidance_scale=6, use_dynamic_cfg=False,
                         eta=0.0, generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None,
                         callback_on_step_end_tensor_inputs=("latents",), max_sequence_length=226, strength=1,
-                        noise_aug_strength=0.0563, inpaint_latents=None, ref_latents=None) -> "DenoiseState":
+                        noise_aug_strength=0.0563, inpaint_latents=None, ref_latents=None,
+                        masked_video_latents=None) -> "DenoiseState":
         """Everything of reference `__call__` before the loop (:786-1087): checks, prompt embeddings, timesteps,
         conditioning latents, initial noise, rotary tables."""
         if num_frames > 49:
@@ -455,7 +473,10 @@ class TrajCrafter_Pipeline:
         # 5. conditioning + latents (:862-1068)
         if inpaint_latents is None or ref_latents is None:
             inpaint_latents, ref_latents = self._build_conditioning(video, mask_video, reference, height, width, do_cfg,
-                                                                    BF16, device, noise_aug_strength)
+                                                                    BF16, device, noise_aug_strength, masked_video_latents)
+        elif masked_video_latents is not None:
+            raise ValueError("`masked_video_latents` only takes part in building the conditioning from pixels; it cannot be "
+                             "combined with pre-encoded `inpaint_latents=` / `ref_latents=`")
         video_length = video.shape[2] if video is not None else num_frames           # quirk: real count = video.shape[2]
         rep = 2 if do_cfg else 1
         inpaint_latents = inpaint_latents.to(device=device, dtype=BF16)
