@@ -63,6 +63,10 @@ int tcx_device_info(int device, int32_t out[4]);
  * kernel then skips the per-workgroup test and the launch of the exact kernel on the (empty) complement: -63 us per call at the
  * product shape.  A false guarantee cannot corrupt memory, but rows whose scores sit more than ~120 below the bound underflow. */
 #define TCX_ATTN_BOUND_PROVEN 2
+/* TCX_ATTN_BODY_16X16X32 (only effective with TCX_ATTN_BOUND_PROVEN, D = 64, bf16 output; ignored otherwise): run the bound-centred
+ * loop on v_mfma_f32_16x16x32_bf16 tiles instead of 32x32x16 (same algorithm, same rounding points, other MFMA shape and lane
+ * layout; results agree to fp32 summation order).  Which body the product uses is decided by measurement. */
+#define TCX_ATTN_BODY_16X16X32 4
 int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o,
                  int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t D,
                  int64_t q_stride_b, int64_t q_stride_s, int64_t q_stride_h,
@@ -261,8 +265,10 @@ int tcx_cl_to_ncthw_frames(const void* x, float* y, int32_t N, int32_t C, int64_
  *       gate[b] = gate_x + b * gate_stride_b; both gates null -> gate = 1 (the plain residual of :833-837).
  * x rows are uniformly strided (ldx).  With rows_per_batch > 0, y and res are [B, rows_per_batch, N] views: row m =
  * (b, r) lives at y + b * y_stride_b + r * ldy (a row range of the joint text+video buffer); with 0 they are flat.
- * Needs N % 8 == 0, K % 128 == 0, ldx % 8 == 0, ldy % 8 == 0 (16-byte row-wise stores); any M.  256 x 256 output tiles (ragged edges are
- * masked), 128 KiB of LDS per workgroup. */
+ * Needs N % 8 == 0, K % 8 == 0, ldx % 8 == 0, ldy % 8 == 0 (16-byte row-wise stores); any M < 2^31.  K % 128 == 0 (every Linear of
+ * the 5B model) runs the plain loop, any other K the zero-filled K-tail instantiation.  256 x 256 output tiles (ragged edges are
+ * masked), 128 KiB of LDS per workgroup.  M <= 8 with the bias epilogue (the AdaLN / time-embedding Linears, M = batch) takes a
+ * weight-streaming dot-product kernel instead of an MFMA tile. */
 #define TCX_GEMM_BIAS 0
 #define TCX_GEMM_BIAS_GELU 1
 #define TCX_GEMM_GATED_RESIDUAL 2

@@ -1,0 +1,32 @@
+"""A/B of the two MFMA bodies of the bound-centred self-attention at the product shape [2, 17776, 48, 64]: interleaved rounds in ONE
+process (cdna_hip_programming.md rule 24), random data, the product's flags (bound proven, tail split).
+usage: python tools/attn_body_bench.py [iters] [rounds]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from trajectorycrafter_amd import ops
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+B, S, H, D = 2, 17776, 48, 64
+g = torch.Generator(device="cuda").manual_seed(0)
+q = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16, generator=g) * (D ** -0.5 * 1.4426950408889634)
+k = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16, generator=g)
+v = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16, generator=g)
+ksq = (k.float() ** 2).sum(-1).amax(1).contiguous()
+flop = 4.0 * S * S * D * H * B
+def t(body16):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=body16)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+for _ in range(2):
+    t(True); t(False)
+res = {True: [], False: []}
+for rep in range(rounds):
+    a, b = t(False), t(True)
+    res[False].append(a); res[True].append(b)
+    print(f"32x32x16 body {a:.3f} ms ({flop / a / 1e9:.0f} TF)   16x16x32 body {b:.3f} ms ({flop / b / 1e9:.0f} TF)   16 vs 32: {100 * (a - b) / a:+.2f} %", flush=True)
+med = lambda x: sorted(x)[len(x) // 2]
+print(f"median: 32x32x16 {med(res[False]):.3f} ms = {flop / med(res[False]) / 1e9:.0f} TF | 16x16x32 {med(res[True]):.3f} ms = {flop / med(res[True]) / 1e9:.0f} TF")

@@ -450,8 +450,7 @@ extern "C" int tcx_qk_layernorm_rope(void* q, void* k, int32_t B, int32_t S, int
         // tokens per wave the 2 x 17776 tokens of the product shape made 1112 blocks = 2.17 rounds of the 512 resident ones (a
         // third round 17 % full: 28 % of the kernel idle).  Size the waves so that ALL of them are resident at once (one round,
         // everybody finishes together); never fewer than 8 tokens (the per-wave parameter loads amortise over them).
-        int ncu = 256, dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        const uint32_t ncu = tcx_cu_count();                  // cached per device; 0 (query failed) -> the MI355X's 256
         const int64_t resident_waves = (int64_t)(ncu > 0 ? ncu : 256) * 8;
         int64_t tpw = ((int64_t)B * S + resident_waves - 1) / resident_waves;
         // per-batch rounding: blocks are per batch item (blockIdx.y), 4 waves each

@@ -33,3 +33,16 @@ extern "C" int tcx_device_info(int device, int32_t out[4]) {
     out[3] = arch;
     return TCX_OK;
 }
+
+uint32_t tcx_cu_count() {
+    static std::atomic<uint32_t> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    uint32_t n = cache[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = (uint32_t)v;
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}

@@ -59,6 +59,9 @@ static inline int tcx_ensure_dynamic_lds(TcxPerDeviceOnce& once, const void* fun
     return TCX_OK;
 }
 
+// number of CUs of the current device, cached per device ordinal (tcx_api.cpp); 0 if it cannot be queried
+uint32_t tcx_cu_count();
+
 // ---- conv dispatch (conv.hip -> conv_mfma.hip) ----
 struct TcxConvArgs {
     const void *x, *cache, *w, *bias, *res;

@@ -192,7 +192,9 @@ class Attention(nn.Module):
         workgroup test nor the exact kernel's launch on the complement (TCX_ATTN_BOUND_PROVEN).  Evaluated once per weight
         version (one host read of 4 x dh numbers); the 1.01 covers the bf16 rounding of q and k and the kernel's 1.002 margin."""
         ws = (self.norm_q.weight, self.norm_q.bias, self.norm_k.weight, self.norm_k.bias)
-        key = tuple(w.data_ptr() for w in ws) + tuple(w._version for w in ws) + (q_scale,)
+        # inference tensors (built / loaded under torch.inference_mode()) track no version counter; they cannot be
+        # modified in place either, so the storage address alone identifies their contents
+        key = tuple(w.data_ptr() for w in ws) + tuple(0 if w.is_inference() else w._version for w in ws) + (q_scale,)
         if self._proven is None or self._proven[0] != key:
             with torch.no_grad():
                 gq, bq, gk, bk = (w.detach().float() for w in ws)
