@@ -135,8 +135,14 @@ def test_attn_fwd_body_16x16x32(ops, B, H, Sq, Sk):
     o32 = ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=False)
     o16 = ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=True)
     assert o16.dtype == BF
-    assert_bf16_close(o16, ref, extra=bound)
-    assert_bf16_close(o16, o32.float().cpu(), extra=bound)
+    # vs the oracle: every element within one bf16 ulp + the P-rounding bound; mean error no worse than the 32x32x16 body's
+    assert_bf16_close(o16, ref, extra=bound, mean_frac=0.5)
+    e16, e32 = float((o16.float().cpu() - ref).abs().mean()), float((o32.float().cpu() - ref).abs().mean())
+    assert e16 <= 1.05 * e32 + 1e-6, (e16, e32)
+    # vs the 32x32x16 body: the exponent origin M = |q| max|k| is summed in another lane order (last-bit differences), so a
+    # probability near a bf16 tie may round the other way: within one output ulp + the same P-rounding bound
+    d = (o16.float() - o32.float()).abs().cpu()
+    assert bool((d <= o32.float().abs().cpu() * 2.0 ** -7 + 1e-5 + bound).all()), float(d.max())
     assert torch.equal(o16, ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=True))
     # without the proven flag the request is ignored (the per-workgroup predicate lives in the 32x32x16 kernels only)
     assert torch.equal(ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, log2_scores=True, k_sqmax=ksq, body16=True),

@@ -7,19 +7,6 @@ tag=${1:-r3}
 R=$GRAFT_REPO_ROOT
 cd $R/trajectorycrafter_amd/csrc
 python3 - <<'PY'
-s = open("attn_fwd.hip").read()
-s = s.replace("    auto run = [&](auto bnd) __attribute__((always_inline)) {",
-              "    const unsigned long long tC0 = __builtin_amdgcn_s_memtime(), tR0 = __builtin_amdgcn_s_memrealtime();\n    __builtin_amdgcn_s_waitcnt(0xC07F);\n    auto run = [&](auto bnd) __attribute__((always_inline)) {")
-s = s.replace("    run(std::integral_constant<bool, BOUND>{});\n", """    run(std::integral_constant<bool, BOUND>{});
-    {
-        const unsigned long long tC1 = __builtin_amdgcn_s_memtime(), tR1 = __builtin_amdgcn_s_memrealtime();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        if (BOUND && (blockIdx.x % 997 == 5) && lane == 0 && (wave == 0 || wave == 7))
-            printf("ASTAMP D %d wg %d wave %d tiles %d cycles %llu real %llu\\n", D, (int)blockIdx.x, wave, ntiles, tC1 - tC0, tR1 - tR0);
-    }
-""")
-assert s.count("ASTAMP") == 1 and s.count("tC0") >= 2
-open("/tmp/attn_clk.hip", "w").write(s)
 g = open("gemm.hip").read()
 g = g.replace("    for (int kt2 = 0; kt2 < KT; kt2 += 2) iteration(std::false_type{}, kt2);\n    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");",
               "    const unsigned long long tC0 = __builtin_amdgcn_s_memtime(), tR0 = __builtin_amdgcn_s_memrealtime();\n    __builtin_amdgcn_s_waitcnt(0xC07F);\n"
@@ -32,12 +19,12 @@ assert g.count("GSTAMP") == 1
 open("/tmp/gemm_clk.hip", "w").write(g)
 PY
 F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -w -I."
-/opt/rocm/bin/hipcc $F -x hip -c /tmp/attn_clk.hip -o /tmp/attn_clk.o && /opt/rocm/bin/hipcc $F -x hip -c /tmp/gemm_clk.hip -o /tmp/gemm_clk.o || exit 1
+/opt/rocm/bin/hipcc $F -DTCX_ATTN_STAMP -x hip -c attn_fwd.hip -o /tmp/attn_clk.o && /opt/rocm/bin/hipcc $F -x hip -c /tmp/gemm_clk.hip -o /tmp/gemm_clk.o || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libtcx_aclk.so tcx_api.o /tmp/attn_clk.o norm.o elementwise.o conv.o conv_mfma.o groupnorm.o warp.o gemm.o || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libtcx_gclk.so tcx_api.o attn_fwd.o norm.o elementwise.o conv.o conv_mfma.o groupnorm.o warp.o /tmp/gemm_clk.o || exit 1
 cd $R
 # ~300 launches of 7 ms = 2 s of attention; the stamps of the LAST launches are the settled ones (tail of the log)
-TCX_LIB=/tmp/libtcx_aclk.so python3 tools/attn_split_bench.py 40 > gpurun_out/${tag}_clock_attn.log 2>&1 || { tail -5 gpurun_out/${tag}_clock_attn.log; exit 1; }
+TCX_LIB=/tmp/libtcx_aclk.so python3 tools/attn_body_bench.py 25 6 > gpurun_out/${tag}_clock_attn.log 2>&1 || { tail -5 gpurun_out/${tag}_clock_attn.log; exit 1; }
 TCX_LIB=/tmp/libtcx_aclk.so python3 tools/microbench.py cross --iters 400 >> gpurun_out/${tag}_clock_attn.log 2>&1
 TCX_LIB=/tmp/libtcx_gclk.so python3 tools/gemm_bench.py 150 > gpurun_out/${tag}_clock_gemm.log 2>&1 || { tail -5 gpurun_out/${tag}_clock_gemm.log; exit 1; }
 python3 - "$tag" <<'PY'
@@ -60,7 +47,7 @@ def med(lines, key):
                   "clock_GHz": round(statistics.median(c / r * 0.1 for c, r in v), 4)}
     return res
 a = [l for l in open(f"gpurun_out/{tag}_clock_attn.log") if l.startswith("ASTAMP")]
-out["kernels"]["attn_fwd_kernel (bound-centred), by head dim"] = med(a, lambda l: "D=" + re.search(r"ASTAMP D (\d+)", l).group(1))
+out["kernels"]["attention main loop (bound-centred), by MFMA body / head dim"] = med(a, lambda l: "body %s, D=%s" % re.search(r"ASTAMP body (\d+) D (\d+)", l).groups())
 g = [l for l in open(f"gpurun_out/{tag}_clock_gemm.log") if l.startswith("GSTAMP")]
 out["kernels"]["gemm_kernel main loop, by epilogue / K iterations"] = med(g, lambda l: "epi %s, %s iterations" % re.search(r"epi (\d+) .* iters (\d+)", l).groups())
 json.dump(out, open(f"gpurun_out/{tag}_clock.json", "w"), indent=1)

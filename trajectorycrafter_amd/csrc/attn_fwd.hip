@@ -254,15 +254,17 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     }
 
     // S^T tile of one 64-key block: 2 x (32 keys x 32 queries); `ks0..ks1` selects a slice of the k-steps
-    auto qk_init = [&](f32x16 (&s)[2]) __attribute__((always_inline)) {
+    // The initial accumulator of a QK^T chain (FAST: the persistent block holding -m, so that S' = K Q^T - m comes straight out of
+    // the MFMA chain; otherwise zero — bound-centred D = 128: |S| <= M < 60, P = exp2(S) needs no centring at all) is the C operand
+    // of the chain's FIRST MFMA, whose destination is the S tile: no per-tile copy of 32 registers (that copy was 32 v_mov per
+    // wave-tile = 18 % of the issue cycles of an issue-bound loop).
+    f32x16 czero;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if constexpr (FAST && !(BOUND && D == 128)) s[t] = minit;      // S' = K Q^T - m straight out of the MFMA chain
-            else {                                 // (bound-centred D = 128: |S| <= M < 60, P = exp2(S) needs no centring at all)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s[t][i] = 0.f;
-            }
-        }
+    for (int i = 0; i < 16; ++i) czero[i] = 0.f;
+    auto chain_c = [&](bool first_of_chain, const f32x16& acc) __attribute__((always_inline)) -> f32x16 {
+        if (!first_of_chain) return acc;
+        if constexpr (FAST && !(BOUND && D == 128)) return minit;
+        else return czero;
     };
     auto qk_part = [&](const char* kb, f32x16 (&s)[2], int ks0, int ks1) __attribute__((always_inline)) {
 #pragma unroll
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(kb + koff[ks] + t * K_T_STRIDE);
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], chain_c(ks == 0, s[t]), 0, 0, 0);
             }
         }
     };
@@ -384,7 +386,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         constexpr bool PREF = (D == 64);             // D = 128 has no registers to spare for a second fragment set
         bf16x8 kfa[KPS][2], kfb[KPS][2], vfa[DT], vfb[DT];
         if constexpr (PREF) read_frags(has_next, kb, vb, 0, kfa, vfa);
-        if constexpr (NEXT) qk_init(nxt);
         auto one_step = [&](int st, bf16x8 (&kf)[KPS][2], bf16x8 (&vf)[DT], bf16x8 (&kfn)[KPS][2], bf16x8 (&vfn)[DT]) __attribute__((always_inline)) {
             const int t = st >> 1, s2 = st & 1;
             if constexpr (PREF) {
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
                 for (int j = 0; j < KPS; ++j)
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt)
-                        nxt[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j][tt], qf[st * KPS + j], nxt[tt], 0, 0, 0);
+                        nxt[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j][tt], qf[st * KPS + j], chain_c(st == 0 && j == 0, nxt[tt]), 0, 0, 0);
             }
             bf16x8 pf;
 #pragma unroll
@@ -483,7 +484,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         };
         if constexpr (NEXT) {
             if constexpr (!PRE) read_k(0, kfa);
-            qk_init(nxt);
         }
         auto step = [&](int st, bf16x8 (&kf)[2], bf16x8 (&kfn)[2]) __attribute__((always_inline)) {
             const int t = st >> 1, s2 = st & 1;
@@ -510,10 +510,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             soft2(2);
             __builtin_amdgcn_sched_barrier(0);
             read_v(st, 1, vcur[1]);
-            if constexpr (NEXT) nxt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[st], nxt[0], 0, 0, 0);
+            if constexpr (NEXT) nxt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[st], chain_c(st == 0, nxt[0]), 0, 0, 0);
             soft2(4);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NEXT) nxt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[st], nxt[1], 0, 0, 0);
+            if constexpr (NEXT) nxt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[st], chain_c(st == 0, nxt[1]), 0, 0, 0);
             soft2(6);
             asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]));
             __builtin_amdgcn_sched_barrier(0);
@@ -538,16 +538,21 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     constexpr std::integral_constant<int, 0> J0{};
     constexpr std::integral_constant<int, TPB - 1> J1{};
     f32x16 sa[2], sb[2];
-    auto one_tile = [&](auto bnd, auto slot_k, auto slot_v, int tile, f32x16 (&cur)[2], f32x16 (&nxt)[2], auto prefetched,
+    // MASK: this tile may compute the scores of the LAST key tile (ragged Sk).  The steady-state loop is instantiated with
+    // MASK = false: hipcc if-converts `if (last) mask_tail(nxt)` into 32 v_cndmask + the predicate arithmetic executed on EVERY
+    // tile (18 % of the issue cycles of this issue-bound loop); only the <= 2 super-steps before the end carry the check.
+    auto one_tile = [&](auto bnd, auto masked, auto slot_k, auto slot_v, int tile, f32x16 (&cur)[2], f32x16 (&nxt)[2], auto prefetched,
                         const char* kb_after) __attribute__((always_inline)) {
         if constexpr (FINE) tile_body_fine(std::true_type{}, prefetched, kbuf0 + decltype(slot_k)::value * TILEB, kb_after,
                                            vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
         else tile_body(std::true_type{}, kbuf0 + decltype(slot_k)::value * TILEB, vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
-        if (tile + 1 == ntiles - 1 && (Sk & 63)) mask_tail(nxt);
+        if constexpr (decltype(masked)::value) {
+            if (tile + 1 == ntiles - 1 && (Sk & 63)) mask_tail(nxt);
+        }
         if constexpr (!decltype(bnd)::value) row_max_and_rescale(nxt);   // bound-centred loop: the reference max never moves
         else __builtin_amdgcn_sched_barrier(0);                         // keep tiles apart (register pressure)
     };
-    auto super_step = [&](auto bnd, auto ph, int t0) __attribute__((always_inline)) {
+    auto super_step = [&](auto bnd, auto masked, auto ph, int t0) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph)::value;
         load_k(J0, t0 + TPB + 1);
         load_v(J0, t0 + TPB);
@@ -557,13 +562,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         }
         if constexpr (TPB == 2) {
             // the second tile's K slot ((PH + 2) % R) is resident for the whole super-step: its first fragments are prefetched
-            one_tile(bnd, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb, std::false_type{},
+            one_tile(bnd, masked, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb, std::false_type{},
                      kbuf0 + ((PH + 2) % R) * TILEB);
-            one_tile(bnd, std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa, std::true_type{},
+            one_tile(bnd, masked, std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa, std::true_type{},
                      nullptr);
         } else {
-            if constexpr (PH == 0) one_tile(bnd, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t0, sa, sb, std::false_type{}, nullptr);
-            else one_tile(bnd, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t0, sb, sa, std::false_type{}, nullptr);
+            if constexpr (PH == 0) one_tile(bnd, masked, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t0, sa, sb, std::false_type{}, nullptr);
+            else one_tile(bnd, masked, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t0, sb, sa, std::false_type{}, nullptr);
         }
 #ifndef TCX_EXP_NOWRITE
         write_k(J0, (PH + TPB + 1) % R);
@@ -584,7 +589,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         const int rem = (ntiles - 1) - t0;                   // 0 .. TPB-1
         if constexpr (TPB == 2) {
             if (rem == 1) {
-                one_tile(bnd, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb, std::false_type{}, nullptr);
+                one_tile(bnd, std::true_type{}, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb, std::false_type{}, nullptr);
                 if constexpr (FINE) tile_body_fine(std::false_type{}, std::false_type{}, kbuf0, nullptr, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
                 else tile_body(std::false_type{}, kbuf0, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
             } else {
@@ -614,26 +619,43 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     load_k(J0, TPB);
     write_k(J0, TPB % R);
     __syncthreads();
-    qk_init(sa);
     qk_part(kbuf0, sa, 0, KS);
     if (ntiles == 1 && (Sk & 63)) mask_tail(sa);
     if constexpr (!bounded) row_max_and_rescale(sa);
     __syncthreads();                      // slot 0 of K is overwritten at the end of the first super-step
 
+#ifdef TCX_ATTN_STAMP                  // diagnostic build only (tools/clock_stamps.sh)
+    const unsigned long long tC0 = __builtin_amdgcn_s_memtime(), tR0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     auto run = [&](auto bnd) __attribute__((always_inline)) {
         int t0 = 0;
-        for (; t0 + 2 * TPB <= ntiles - 1; t0 += 2 * TPB) {
-            super_step(bnd, std::integral_constant<int, 0>{}, t0);
-            super_step(bnd, std::integral_constant<int, TPB>{}, t0 + TPB);
+        // steady state: a pair of super-steps computes the scores up to tile t0 + 2 TPB; while that is not the last tile: no mask
+        for (; t0 + 2 * TPB < ntiles - 1; t0 += 2 * TPB) {
+            super_step(bnd, std::false_type{}, std::integral_constant<int, 0>{}, t0);
+            super_step(bnd, std::false_type{}, std::integral_constant<int, TPB>{}, t0 + TPB);
+        }
+        if (t0 + 2 * TPB <= ntiles - 1) {                    // the pair that reaches the last tile exactly
+            super_step(bnd, std::true_type{}, std::integral_constant<int, 0>{}, t0);
+            super_step(bnd, std::true_type{}, std::integral_constant<int, TPB>{}, t0 + TPB);
+            t0 += 2 * TPB;
         }
         if (t0 + TPB <= ntiles - 1) {
-            super_step(bnd, std::integral_constant<int, 0>{}, t0);
+            super_step(bnd, std::true_type{}, std::integral_constant<int, 0>{}, t0);
             tail(bnd, std::integral_constant<int, TPB>{}, t0 + TPB);
         } else {
             tail(bnd, std::integral_constant<int, 0>{}, t0);
         }
     };
     run(std::integral_constant<bool, BOUND>{});
+#ifdef TCX_ATTN_STAMP
+    {
+        const unsigned long long tC1 = __builtin_amdgcn_s_memtime(), tR1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (BOUND && (blockIdx.x % 997 == 5) && lane == 0 && (wave == 0 || wave == 7))
+            printf("ASTAMP body 32 D %d wg %d wave %d tiles %d cycles %llu real %llu\n", D, (int)blockIdx.x, wave, ntiles, tC1 - tC0, tR1 - tR0);
+    }
+#endif
     if constexpr (FINE) {                 // the delayed PV product of the very last 16-key step
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vprev[dt], pprev, o[dt], 0, 0, 0);
@@ -825,7 +847,13 @@ __global__ __launch_bounds__(512) void attn_fwd16_kernel(const AttnParams p) {
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float ls[2][2] = {{0.f, 0.f}, {0.f, 0.f}};            // [qt][chain]: per-lane partial row sums
+    // row sums on the matrix pipe: ones(16 x 32) . P^T, one more MFMA per P operand (4 per tile, +12 % matrix work) instead of 32 v_add
+    // per tile in a loop whose limiter is the SIMD's instruction issue: +3.3 % measured (tools/attn_body_bench.py), and numerator and
+    // denominator now use the SAME bf16-rounded P (the oracle's contract, dr.sdpa_log2).  Every row of the product holds the sums.
+    f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
     f32x4 sa[4][2], sb[4][2];                              // S^T of the current / next tile: [kt][qt]
     bf16x8 pprev, vfa[4], vfb[4], kfa[2], kfb[2];
 #pragma unroll
@@ -833,12 +861,10 @@ __global__ __launch_bounds__(512) void attn_fwd16_kernel(const AttnParams p) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) vfa[dt] = vfb[dt] = pprev;
 
-    auto qk_init = [&](f32x4 (&s)[4][2]) __attribute__((always_inline)) {
+    // -M as the C operand of the first MFMA of every QK^T chain (destination = the S tile): S' = K Q^T - M with no per-tile copies
+    f32x4 cinit[2];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) s[kt][qt] = f32x4{negM[qt], negM[qt], negM[qt], negM[qt]};   // S' = K Q^T - M out of the MFMA chain
-    };
+    for (int qt = 0; qt < 2; ++qt) cinit[qt] = f32x4{negM[qt], negM[qt], negM[qt], negM[qt]};
     auto read_k = [&](const char* kb, int kt, bf16x8 (&kf)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(kb + koff[kt & 1][ks] + kt * 2048);
@@ -883,7 +909,6 @@ __global__ __launch_bounds__(512) void attn_fwd16_kernel(const AttnParams p) {
         float e[8];
         auto soft = [&](int i) __attribute__((always_inline)) {
             e[i] = __builtin_amdgcn_exp2f(cur[2 * KK + (i >> 2)][QT][i & 3]);
-            ls[QT][i & 1] += e[i];
             if (i & 1) {
                 uint32_t w = pack_bf16(e[i - 1], e[i]);
                 asm volatile("" : "+v"(w));               // convert here, in this gap
@@ -893,24 +918,21 @@ __global__ __launch_bounds__(512) void attn_fwd16_kernel(const AttnParams p) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             o[dt][QP] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pprev, o[dt][QP], 0, 0, 0);
+            if (dt == 3) lacc[QP] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pprev, lacc[QP], 0, 0, 0);
             soft(dt);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            if constexpr (NEXT) nxt[J][n & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[n >> 1], qf[n & 1][n >> 1], nxt[J][n & 1], 0, 0, 0);
+            if constexpr (NEXT) nxt[J][n & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[n >> 1], qf[n & 1][n >> 1], n < 2 ? cinit[n & 1] : nxt[J][n & 1], 0, 0, 0);
             soft(4 + n);
-            if (n == 3) asm volatile("" : "+v"(ls[0][0]), "+v"(ls[0][1]), "+v"(ls[1][0]), "+v"(ls[1][1]));
             __builtin_amdgcn_sched_barrier(0);
         }
         pprev = __builtin_bit_cast(bf16x8, pw);
     };
     auto tile = [&](auto has_next, const char* kb, const char* vb, f32x4 (&cur)[4][2], f32x4 (&nxt)[4][2]) __attribute__((always_inline)) {
         constexpr bool NEXT = decltype(has_next)::value;
-        if constexpr (NEXT) {
-            read_k(kb, 0, kfa);
-            qk_init(nxt);
-        }
+        if constexpr (NEXT) read_k(kb, 0, kfa);
         step(has_next, std::integral_constant<int, 0>{}, kb, vb, cur, nxt, kfa, kfb);
         step(has_next, std::integral_constant<int, 1>{}, kb, vb, cur, nxt, kfb, kfa);
         step(has_next, std::integral_constant<int, 2>{}, kb, vb, cur, nxt, kfa, kfb);
@@ -919,20 +941,22 @@ __global__ __launch_bounds__(512) void attn_fwd16_kernel(const AttnParams p) {
 
     constexpr std::integral_constant<int, 0> J0{};
     constexpr std::integral_constant<int, 1> J1{};
-    auto one_tile = [&](auto slot_k, auto slot_v, int t, f32x4 (&cur)[4][2], f32x4 (&nxt)[4][2]) __attribute__((always_inline)) {
+    auto one_tile = [&](auto masked, auto slot_k, auto slot_v, int t, f32x4 (&cur)[4][2], f32x4 (&nxt)[4][2]) __attribute__((always_inline)) {
         tile(std::true_type{}, kbuf0 + decltype(slot_k)::value * TILEB, vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
-        if (t + 1 == ntiles - 1 && (Sk & 63)) mask_tail(nxt);
+        if constexpr (decltype(masked)::value) {          // only the super-steps that can reach the last key tile (see attn_fwd_kernel)
+            if (t + 1 == ntiles - 1 && (Sk & 63)) mask_tail(nxt);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     // ring / barrier structure of attn_fwd_kernel (see there): tile t in slot t % R; a super-step = 2 tiles, one barrier
-    auto super_step = [&](auto ph, int t0) __attribute__((always_inline)) {
+    auto super_step = [&](auto masked, auto ph, int t0) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph)::value;
         load_k(J0, t0 + TPB + 1);
         load_v(J0, t0 + TPB);
         load_k(J1, t0 + TPB + 2);
         load_v(J1, t0 + TPB + 1);
-        one_tile(std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
-        one_tile(std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa);
+        one_tile(masked, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
+        one_tile(masked, std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa);
         write_k(J0, (PH + TPB + 1) % R);
         write_v(J0, (PH + TPB) % R);
         write_k(J1, (PH + TPB + 2) % R);
@@ -943,7 +967,7 @@ __global__ __launch_bounds__(512) void attn_fwd16_kernel(const AttnParams p) {
         constexpr int PH = decltype(ph)::value;
         const int rem = (ntiles - 1) - t0;                 // 0 or 1 tiles with a successor, then the last tile
         if (rem == 1) {
-            one_tile(std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
+            one_tile(std::true_type{}, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
             tile(std::false_type{}, kbuf0, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
         } else {
             tile(std::false_type{}, kbuf0, vbuf0 + (PH % R) * TILEB, sa, sb);
@@ -962,43 +986,53 @@ __global__ __launch_bounds__(512) void attn_fwd16_kernel(const AttnParams p) {
     load_k(J0, TPB);
     write_k(J0, TPB % R);
     __syncthreads();
-    qk_init(sa);
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
         read_k(kbuf0, kt, kfa);
 #pragma unroll
         for (int n = 0; n < 4; ++n)
-            sa[kt][n & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfa[n >> 1], qf[n & 1][n >> 1], sa[kt][n & 1], 0, 0, 0);
+            sa[kt][n & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfa[n >> 1], qf[n & 1][n >> 1], n < 2 ? cinit[n & 1] : sa[kt][n & 1], 0, 0, 0);
     }
     if (ntiles == 1 && (Sk & 63)) mask_tail(sa);
     __syncthreads();
 
+#ifdef TCX_ATTN_STAMP                  // diagnostic build only (tools/clock_stamps.sh): cycles and 100 MHz ticks around the main loop
+    const unsigned long long tC0 = __builtin_amdgcn_s_memtime(), tR0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     {
         int t0 = 0;
-        for (; t0 + 2 * TPB <= ntiles - 1; t0 += 2 * TPB) {
-            super_step(std::integral_constant<int, 0>{}, t0);
-            super_step(std::integral_constant<int, TPB>{}, t0 + TPB);
+        for (; t0 + 2 * TPB < ntiles - 1; t0 += 2 * TPB) {   // steady state: never reaches the last key tile -> no mask code
+            super_step(std::false_type{}, std::integral_constant<int, 0>{}, t0);
+            super_step(std::false_type{}, std::integral_constant<int, TPB>{}, t0 + TPB);
+        }
+        if (t0 + 2 * TPB <= ntiles - 1) {
+            super_step(std::true_type{}, std::integral_constant<int, 0>{}, t0);
+            super_step(std::true_type{}, std::integral_constant<int, TPB>{}, t0 + TPB);
+            t0 += 2 * TPB;
         }
         if (t0 + TPB <= ntiles - 1) {
-            super_step(std::integral_constant<int, 0>{}, t0);
+            super_step(std::true_type{}, std::integral_constant<int, 0>{}, t0);
             tail(std::integral_constant<int, TPB>{}, t0 + TPB);
         } else {
             tail(std::integral_constant<int, 0>{}, t0);
         }
     }
+#ifdef TCX_ATTN_STAMP
+    {
+        const unsigned long long tC1 = __builtin_amdgcn_s_memtime(), tR1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if ((blockIdx.x % 997 == 5) && lane == 0 && (wave == 0 || wave == 7))
+            printf("ASTAMP body 16 D 64 wg %d wave %d tiles %d cycles %llu real %llu\n", (int)blockIdx.x, wave, ntiles, tC1 - tC0, tR1 - tR0);
+    }
+#endif
     // the delayed PV product of the very last step (key pair 1 -> V set B, query tile 1)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfb[dt], pprev, o[dt][1], 0, 0, 0);
+    lacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pprev, lacc[1], 0, 0, 0);
 
-    // ---- epilogue: row sums over the 4 lanes of a query row, normalise, store ----
-    float l[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        float x = ls[qt][0] + ls[qt][1];
-        x += __shfl_xor(x, 16);
-        x += __shfl_xor(x, 32);
-        l[qt] = x;
-    }
+    // ---- epilogue: normalise, store ----
+    const float l[2] = {lacc[0][0], lacc[1][0]};           // every row of ones . P^T holds the row sums over all keys (all four g)
     if (part >= 0) {                                        // split part: un-normalised O (fp32) and the row sum go to the workspace
         const uint32_t items = p.split * (p.nwg - p.n_full);
 #pragma unroll

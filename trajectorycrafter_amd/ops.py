@@ -56,8 +56,9 @@ def attn_timing_stop() -> dict:
     return {d: {"n": len(ev), "ms": float(sum(a.elapsed_time(b) for a, b in ev))} for d, ev in rec.items()}
 
 
-# which MFMA body the bound-proven D = 64 self-attention runs (DESIGN §3.1 records the A/B that decides it)
-ATTN_BODY16_DEFAULT = False
+# which MFMA body the bound-proven D = 64 self-attention runs: the 16x16x32 body, +5.4 % over the 32x32x16 body in interleaved A/B
+# at the product shape (tools/attn_body_bench.py; DESIGN §3.1 records the numbers and the in-kernel clocks)
+ATTN_BODY16_DEFAULT = True
 
 
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
