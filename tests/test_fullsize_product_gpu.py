@@ -110,9 +110,10 @@ def test_self_attention_shipped_path_fullsize(ops, gpu, rotary):
 
     # (2b) TCX_ATTN_BOUND_PROVEN (what the model passes when the LayerNorm parameters prove M < 60): no per-workgroup test, no
     #      complement launch -> the same bits
+    assert torch.equal(ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True), o)
     assert torch.equal(ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=False), o)
-    # ... and the product default with the flag, the 16x16x32 body (its own full-size test below): same rows, same bounds
-    o16 = ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True)
+    # ... and the optional 16x16x32 body (its own full-size test below): same rows, same bounds
+    o16 = ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=True)
     for h in heads:
         for b in range(B):
             err = (o16[b, rows, h].float() - _softmax2_rows(q[b, rows, h], k[b, :, h], v[b, :, h])).abs()

@@ -453,6 +453,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 #else
     constexpr bool FINE = BOUND && FAST && D == 64 && !kSumMfma;
 #endif
+    // Row sums of the fine loop: 32 v_add per tile (default) or one ones . P^T MFMA per 16-key step (-DTCX_ATTN_FINE_SUM_MFMA).  On
+    // THIS body the MFMA form loses 6 % (7.24 vs 6.83 ms, tools/exp/attn_variants.sh, round 3; round 2 measured the same on the coarse
+    // loop): 20 instead of 16 32x32x16 MFMAs per tile put the matrix pipe at 76 % of the tile time and the kernel at 256 VGPRs with
+    // spills — whereas the 16x16x32 body below gains 3.3 % from it (its extra MFMA is 16 cycles, its issue budget the tighter one).
+#ifdef TCX_ATTN_FINE_SUM_MFMA
+    constexpr bool FSUM = FINE;
+#else
+    constexpr bool FSUM = false;
+#endif
     bf16x8 pprev, vprev[DT];
 #pragma unroll
     for (int j = 0; j < 8; ++j) pprev[j] = (__bf16)0.0f;
@@ -492,8 +501,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             auto soft2 = [&](int j0) __attribute__((always_inline)) {
                 const float e0 = __builtin_amdgcn_exp2f(cur[t][8 * s2 + j0]);
                 const float e1 = __builtin_amdgcn_exp2f(cur[t][8 * s2 + j0 + 1]);
-                ls[j0 & 3] += e0;
-                ls[(j0 + 1) & 3] += e1;
+                if constexpr (!FSUM) {
+                    ls[j0 & 3] += e0;
+                    ls[(j0 + 1) & 3] += e1;
+                }
                 uint32_t w = pack_bf16(e0, e1);
                 asm volatile("" : "+v"(w));              // convert here, inside this MFMA gap (the compiler sinks all four to the step's end)
                 pw[j0 >> 1] = w;
@@ -507,6 +518,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             __builtin_amdgcn_sched_barrier(0);
             read_v(st, 0, vcur[0]);
             o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vprev[1], pprev, o[1], 0, 0, 0);
+            if constexpr (FSUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pprev, lacc, 0, 0, 0);
             soft2(2);
             __builtin_amdgcn_sched_barrier(0);
             read_v(st, 1, vcur[1]);
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (NEXT) nxt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[st], chain_c(st == 0, nxt[1]), 0, 0, 0);
             soft2(6);
-            asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]));
+            if constexpr (!FSUM) asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]));
             __builtin_amdgcn_sched_barrier(0);
             pf = __builtin_bit_cast(bf16x8, pw);
             pprev = pf;
@@ -659,11 +671,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     if constexpr (FINE) {                 // the delayed PV product of the very last 16-key step
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vprev[dt], pprev, o[dt], 0, 0, 0);
+        if constexpr (FSUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pprev, lacc, 0, 0, 0);
     }
-    if constexpr (!(FAST && kSumMfma)) l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+    if constexpr (!(FAST && kSumMfma) && !FSUM) l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
 
     // ---- epilogue: combine the two half-wave partial sums, normalise, store O[q][d] ----
-    if constexpr (FAST && kSumMfma) {
+    if constexpr ((FAST && kSumMfma) || FSUM) {
         l = lacc[0];                      // every row of the ones-product holds the full row sum (both half-waves)
     } else {
         const uint32_t u = __float_as_uint(l);

@@ -56,9 +56,11 @@ def attn_timing_stop() -> dict:
     return {d: {"n": len(ev), "ms": float(sum(a.elapsed_time(b) for a, b in ev))} for d, ev in rec.items()}
 
 
-# which MFMA body the bound-proven D = 64 self-attention runs: the 16x16x32 body, +5.4 % over the 32x32x16 body in interleaved A/B
-# at the product shape (tools/attn_body_bench.py; DESIGN §3.1 records the numbers and the in-kernel clocks)
-ATTN_BODY16_DEFAULT = True
+# Which MFMA body the bound-proven D = 64 self-attention runs.  Round-3 A/B: the 16x16x32 body needs 13 % more cycles
+# and holds a 14-17 % higher clock — standalone (attention back to back) it is 3.7 % faster (6.58 vs 6.83 ms), inside the full
+# denoising step, where GEMMs share the power budget, 3.8 % SLOWER (7.27 vs 7.00 ms, tools/step_ab.py, 6 interleaved blocks) on one
+# box and +-1 % on another.  The product keeps the body whose result does not depend on clock headroom.
+ATTN_BODY16_DEFAULT = False
 
 
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
