@@ -99,6 +99,25 @@ def test_transformer_forward_tiny(golden, gpu):
                                   t["timestep"], t["inpaint_latents"], t["cross_latents"], (t["rope_cos"], t["rope_sin"]),
                                   prec="bf16")
     _check_deep(out, ref, t["out_sample"], "transformer tiny (2 blocks + cross-attention)")
+    # opt-in reuse of the reference-token K / V (model.cache_cross_kv): bit-identical, reused while the SAME cross_latents tensor
+    # comes back (the pipeline's `ref_input`), recomputed when it is modified in place or replaced
+    cl = t["cross_latents"].to(gpu, BF)
+    call = lambda c: model(t["hidden_states"].to(gpu, BF), t["encoder_hidden_states"].to(gpu, BF), t["timestep"].to(gpu),
+                           inpaint_latents=t["inpaint_latents"].to(gpu, BF), cross_latents=c, image_rotary_emb=rot, return_dict=False)[0]
+    model.cache_cross_kv = True
+    try:
+        a = call(cl)
+        key0 = model._cross_kv_cache[0]
+        b = call(cl)
+        assert torch.equal(a, out) and torch.equal(b, out) and model._cross_kv_cache[0] == key0
+        cl.mul_(-1.0)                                           # in-place change -> version counter -> recomputed
+        c = call(cl)
+        assert model._cross_kv_cache[0] != key0 and not torch.equal(c, out)
+        model.cache_cross_kv = False
+        assert torch.equal(call(cl), c)
+    finally:
+        model.cache_cross_kv = False
+        model._cross_kv_cache = None
 
 
 def test_transformer_block_and_cross_attention_signatures(golden, gpu):

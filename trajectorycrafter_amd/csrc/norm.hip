@@ -184,6 +184,118 @@ __global__ __launch_bounds__(256) void ln_modulate_rows_kernel(const LnParams p)
     }
 }
 
+// Round 3: the row-looping kernel with the modulation folded ONCE per workgroup into two fp32 vectors in LDS,
+//     A = gamma (1 + scale),   Bc = beta (1 + scale) + shift        =>   y = ((x - mean) rstd) A + Bc,
+// (identical to ((x - mean) rstd gamma + beta)(1 + scale) + shift up to fp32 rounding order; one rounding to bf16 at the store as
+// before).  Why: with the four bf16 parameter vectors resident in registers the round-2 kernel sat at 219 VGPRs = 2 waves per SIMD
+// AND spent ~20 VALU operations per element (4 unpacks + 5 arithmetic per element in the apply pass alone): at 8 waves per CU
+// neither the 437 MB of HBM traffic nor the ~63 us of vector work per launch was hidden behind the other (3.9 TB/s).  Here a lane
+// reads its chunk's A / Bc by two ds_read_b128 each (two planes per vector, 16 bytes per lane: conflict-free), the apply pass is
+// 3 VALU per element, and the kernel needs < 100 VGPRs: 24 KiB of LDS per workgroup -> 6 workgroups = 24 waves per CU.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_modulate_lds_kernel(const LnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char ln_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y >> 1, vid = blockIdx.y & 1;
+    const int seg0 = vid ? p.text_len : 0, seg1 = vid ? p.rows : p.text_len;
+    const int rb = seg0 + (int)blockIdx.x * (4 * p.rows_per_wave);          // first row of this workgroup
+    if (rb >= seg1) return;                                                  // workgroup-uniform: before any barrier
+    const int nchunk = p.C >> 3;
+    f32x4* const Alo = reinterpret_cast<f32x4*>(ln_lds);                     // planes of nchunk x 16 bytes: A[8 ch + 0..3], A[8 ch + 4..7],
+    f32x4* const Ahi = Alo + nchunk;                                         // Bc likewise
+    f32x4* const Blo = Ahi + nchunk;
+    f32x4* const Bhi = Blo + nchunk;
+    {
+        const uint16_t* sh = vid ? p.shift_v : p.shift_t;
+        const uint16_t* sc = vid ? p.scale_v : p.scale_t;
+        if (sh) sh += (int64_t)b * p.msb;
+        if (sc) sc += (int64_t)b * p.msb;
+        for (int ch = threadIdx.x; ch < nchunk; ch += 256) {
+            float g[8], be[8], s1[8], s2[8], A[8], Bc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { g[e] = 1.f; be[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+            if (p.gamma) unpack8(*reinterpret_cast<const u32x4*>(p.gamma + 8 * ch), g);
+            if (p.beta) unpack8(*reinterpret_cast<const u32x4*>(p.beta + 8 * ch), be);
+            if (sc) unpack8(*reinterpret_cast<const u32x4*>(sc + 8 * ch), s1);
+            if (sh) unpack8(*reinterpret_cast<const u32x4*>(sh + 8 * ch), s2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float m = 1.0f + s1[e];
+                A[e] = g[e] * m;
+                Bc[e] = __builtin_fmaf(be[e], m, s2[e]);
+            }
+            Alo[ch] = f32x4{A[0], A[1], A[2], A[3]};
+            Ahi[ch] = f32x4{A[4], A[5], A[6], A[7]};
+            Blo[ch] = f32x4{Bc[0], Bc[1], Bc[2], Bc[3]};
+            Bhi[ch] = f32x4{Bc[4], Bc[5], Bc[6], Bc[7]};
+        }
+    }
+    __syncthreads();
+    const int r0 = rb + wv;                                                  // this wave: r0, r0 + 4, ...
+    if (r0 >= seg1) return;
+    const uint16_t* xb = p.x + (int64_t)b * p.xsb;
+    uint16_t* yb = p.y + (int64_t)b * p.ysb;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    u32x4 raw[NCH], nraw[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = j * 64 + lane;
+        raw[j] = ch < nchunk ? *reinterpret_cast<const u32x4*>(xb + (int64_t)r0 * p.C + 8 * ch) : zero4;
+    }
+    const float invC = 1.0f / (float)p.C;
+    for (int i = 0; i < p.rows_per_wave; ++i) {
+        const int r = r0 + 4 * i;
+        if (r >= seg1) break;
+        const bool more = i + 1 < p.rows_per_wave && r + 4 < seg1;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = j * 64 + lane;
+            nraw[j] = (more && ch < nchunk) ? *reinterpret_cast<const u32x4*>(xb + (int64_t)(r + 4) * p.C + 8 * ch) : zero4;
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            float v[8];
+            unpack8(raw[j], v);                          // chunks past the row are zero: they add nothing to the sum
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += v[e];
+        }
+        const float mean = wave_sum(sum) * invC;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (j * 64 + lane < nchunk) {
+                float v[8];
+                unpack8(raw[j], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[e] - mean;
+                    sq = __builtin_fmaf(d, d, sq);
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) * invC + p.eps);
+        uint16_t* yr = yb + (int64_t)r * p.C;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = j * 64 + lane;
+            if (ch < nchunk) {
+                const f32x4 a0 = Alo[ch], a1 = Ahi[ch], c0 = Blo[ch], c1 = Bhi[ch];
+                float v[8], out[8];
+                unpack8(raw[j], v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    out[e] = __builtin_fmaf((v[e] - mean) * rstd, a0[e], c0[e]);
+                    out[4 + e] = __builtin_fmaf((v[4 + e] - mean) * rstd, a1[e], c1[e]);
+                }
+                *reinterpret_cast<u32x4*>(yr + 8 * ch) = pack8(out);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) raw[j] = nraw[j];
+    }
+}
+
 struct QkParams {
     uint16_t *q, *k;
     int32_t B, S, H;
@@ -403,15 +515,31 @@ extern "C" int tcx_layernorm_modulate(const void* x, void* y, int32_t B, int32_t
     if (total >= 4096 && nch <= 6 && B <= 32767) {       // large inputs: row-looping kernel, parameters in registers
         const int tl = (shift_t || scale_t) ? text_len : 0;   // no text modulation: one segment per batch item
         p.text_len = tl;
-        // 8 rows per wave.  (Sizing the waves so that all working blocks are resident in ONE round — 18 rows at the product shape,
-        // 488 blocks on 512 slots instead of 1098 = 2.14 rounds — measured 11 % SLOWER in a same-box A/B, 0.126 vs 0.113 ms: waves
-        // that all start together load and compute in lockstep; the ragged multi-round schedule overlaps them.  The q/k LN + RoPE
-        // kernel below gains 5 % from the same sizing, tools/exp_norm.sh.)
+        // Rows per wave.  Round 3, LDS-parameter kernel (tools/exp/norm_variants.sh, alternating A/B on one box, product shape):
+        // 1: 0.096-0.098 ms | 2: 0.095 | 3: 0.097 | 4: 0.098 | 8: 0.106 | 16: 0.114 | 35 (one round): 0.117 — a wave has one row
+        // in flight besides the one it reduces, so short waves (many workgroups, staggered phases) stream better, and the 24 KiB
+        // parameter set-up per workgroup is cheap enough to repeat every 8 rows.  (The round-2 register-parameter kernel at 8 rows:
+        // 0.112 ms; sizing IT to one resident round had measured 11 % slower.)
         const int seg = tl > rows - tl ? tl : rows - tl;
+#ifdef TCX_NORM_EXP_RPW
+        const int64_t rpw = TCX_NORM_EXP_RPW;
+#elif defined(TCX_NORM_EXP_REGPARAMS)
         const int64_t rpw = 8;
+#else
+        const int64_t rpw = 2;
+#endif
         p.rows_per_wave = (int32_t)rpw;
         const int per_block = 4 * (int)rpw;
         dim3 g2((unsigned)((seg + per_block - 1) / per_block), (unsigned)(2 * B));
+#ifndef TCX_NORM_EXP_REGPARAMS         // A/B builds only: the round-2 kernel with the four parameter vectors in registers
+        {
+            const size_t lds = (size_t)C * 8;            // A and Bc as fp32: 24 KiB at C = 3072 (< the 64 KiB default limit up to C = 8192)
+            if (nch <= 2) hipLaunchKernelGGL(ln_modulate_lds_kernel<2>, g2, block, lds, st, p);
+            else if (nch <= 4) hipLaunchKernelGGL(ln_modulate_lds_kernel<4>, g2, block, lds, st, p);
+            else hipLaunchKernelGGL(ln_modulate_lds_kernel<6>, g2, block, lds, st, p);
+            TCX_LAUNCH_RET();
+        }
+#endif
         if (nch <= 2) hipLaunchKernelGGL(ln_modulate_rows_kernel<2>, g2, block, 0, st, p);
         else if (nch <= 4) hipLaunchKernelGGL(ln_modulate_rows_kernel<4>, g2, block, 0, st, p);
         else hipLaunchKernelGGL(ln_modulate_rows_kernel<6>, g2, block, 0, st, p);

@@ -315,23 +315,31 @@ class PerceiverCrossAttention(nn.Module):
         self.to_kv = nn.Linear(dim if kv_dim is None else kv_dim, inner_dim * 2, bias=False)
         self.to_out = nn.Linear(inner_dim, dim, bias=False)
 
-    def forward(self, x: torch.Tensor, latents: torch.Tensor, add_to_latents: bool = False) -> torch.Tensor:
+    def reference_kv(self, x: torch.Tensor):
+        """The reference-token side of the layer, :379,385,392: (k * scale, max|k|^2 per head, v) from x [B,Sr,D].  It depends on
+        the reference tokens and this layer's weights only — not on the timestep or the video tokens."""
+        H, dh = self.heads, self.dim_head
+        xn = ops.layernorm_modulate(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)          # :379
+        kv = _linear(xn, self.to_kv.weight)                                                          # :385
+        k, v = kv.chunk(2, dim=-1)
+        k, ksq = ops.scale_sqmax(k, 1.0 / math.sqrt(math.sqrt(dh)), H, dh)
+        return k, ksq, v
+
+    def forward(self, x: torch.Tensor, latents: torch.Tensor, add_to_latents: bool = False, kv=None) -> torch.Tensor:
         """x: reference tokens [B,Sr,D]; latents: video tokens [B,Sv,D] (may be a strided row range).
-        add_to_latents: `latents += to_out(...)` in the projection's epilogue (the caller's residual, reference :833-837)."""
+        add_to_latents: `latents += to_out(...)` in the projection's epilogue (the caller's residual, reference :833-837).
+        kv: a `reference_kv(x)` result to use instead of recomputing it (CrossTransformer3DModel.cache_cross_kv)."""
         _require_hip(latents, "PerceiverCrossAttention")
         B, Sv, _ = latents.shape
         H, dh = self.heads, self.dim_head
-        xn = ops.layernorm_modulate(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)          # :379
         ln = ops.layernorm_modulate(latents, self.norm2.weight, self.norm2.bias, self.norm2.eps)    # :380
         s = 1.0 / math.sqrt(math.sqrt(dh))
         q = _linear(ln, self.to_q.weight)                                                            # :384
-        kv = _linear(xn, self.to_kv.weight)                                                          # :385
-        k, v = kv.chunk(2, dim=-1)
         # :392: q * scale and k * scale, each rounded before QK^T.  q additionally carries log2(e) (one rounding, as in the
         # self-attention) so that the attention kernel works on base-2 scores; k's pass also yields max |k|^2 per head, the
         # bound of the bound-centred loop (1068 vs 913 TF for the exact-tracking loop on this shape)
         q = ops.scale_bf16(q, s * LOG2E, out=q)
-        k, ksq = ops.scale_sqmax(k, s, H, dh)
+        k, ksq, v = self.reference_kv(x) if kv is None else kv
         o = ops.attn_fwd(q.view(B, Sv, H, dh), k.view(B, -1, H, dh), v.view(B, -1, H, dh), 1.0, log2_scores=True, k_sqmax=ksq)   # :392-395
         if add_to_latents:
             return _linear(o.view(B, Sv, H * dh), self.to_out.weight, None, ops.GEMM_GATED_RESIDUAL, res=latents)
@@ -515,7 +523,11 @@ class CrossTransformer3DModel(ModelMixin, ConfigMixin):
         # 2. patch embedding into the joint buffer (:736-737)
         text_len = encoder_hidden_states.shape[1]
         x = self.patch_embed(encoder_hidden_states, hidden_states, inpaint_latents.to(BF16))
-        cross_hidden_states = self.ref_patch_embed(cross_latents.to(BF16)) if self.is_train_cross else None
+        cross_hidden_states = cross_kv = None
+        if self.is_train_cross:
+            cross_kv = self._cached_cross_kv(cross_latents) if self.cache_cross_kv else None
+            if cross_kv is None:
+                cross_hidden_states = self.ref_patch_embed(cross_latents.to(BF16))
 
         rotary = None
         if image_rotary_emb is not None:
@@ -529,7 +541,8 @@ class CrossTransformer3DModel(ModelMixin, ConfigMixin):
         for i, block in enumerate(self.transformer_blocks):
             block.forward_joint(x, text_len, silu_emb, rotary)
             if self.is_train_cross and i % self.cross_attn_interval == 0:
-                self.perceiver_cross_attention[ca_idx](cross_hidden_states, video, add_to_latents=True)   # :833-837
+                self.perceiver_cross_attention[ca_idx](cross_hidden_states, video, add_to_latents=True,
+                                                       kv=None if cross_kv is None else cross_kv[ca_idx])     # :833-837
                 ca_idx += 1
 
         # norm_final is row-wise: the reference's cat(text, video) -> LN -> drop text (:848-850) == LN(video rows)
@@ -542,6 +555,26 @@ class CrossTransformer3DModel(ModelMixin, ConfigMixin):
         if not return_dict:
             return (output,)
         return Transformer2DModelOutput(sample=output)
+
+    # ---- opt-in: reuse of the reference-token K / V across denoising steps ----
+    # `to_kv(norm1(ref_patch_embed(cross_latents)))` (+ the k scaling) of the 21 cross-attention layers is a function of the
+    # reference latents and the weights only: identical in all 50 steps of a clip (and in both CFG halves).  The reference
+    # recomputes it every step (:833-837) and so does this model by default — the benchmark's step does all the reference's
+    # work.  With `model.cache_cross_kv = True` the 21 (k, max|k|^2, v) triples are computed on the first forward that sees a
+    # given `cross_latents` tensor (same storage, same version counter, same shape) and reused afterwards: bit-identical
+    # outputs, ~2.1 GB of HBM at 480x720, -0.8 % per step.
+    cache_cross_kv = False
+    _cross_kv_cache = None
+
+    def _cached_cross_kv(self, cross_latents: torch.Tensor):
+        wkey = tuple((m.to_kv.weight.data_ptr(), 0 if m.to_kv.weight.is_inference() else m.to_kv.weight._version)
+                     for m in self.perceiver_cross_attention[:1])
+        key = (cross_latents.data_ptr(), 0 if cross_latents.is_inference() else cross_latents._version, tuple(cross_latents.shape),
+               cross_latents.dtype, wkey)
+        if self._cross_kv_cache is None or self._cross_kv_cache[0] != key:
+            ref = self.ref_patch_embed(cross_latents.to(BF16))
+            self._cross_kv_cache = (key, [m.reference_kv(ref) for m in self.perceiver_cross_attention])
+        return self._cross_kv_cache[1]
 
     # ---- checkpoint loaders (:873-1092) ----
     # parameters the reference adds on top of the CogVideoX-Fun checkpoint (`is_train_cross`, :565-579): the only ones a
