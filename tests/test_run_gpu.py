@@ -80,3 +80,35 @@ def test_generate_entry_point_on_a_checkpoint_dir(golden, tmp_path):
 
     r3 = _run(["generate", "--model-dir", str(ckpt), "--conditioning", cond, "--out", out, "--sampler", "DPM++"])
     assert r3.returncode != 0 and "not built" in r3.stderr
+
+
+def test_orbits_entry_point_single_process(golden, tmp_path):
+    """`python -m trajectorycrafter_amd.run orbits` (world size 1 = the reference's sequential loop over the variants,
+    inference_orbits.py:285-300) on a checkpoint directory + a clip file (frames, depths, K, prompt embeddings): equal to
+    `driver.run_orbits` called in process on the same inputs."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from safetensors.torch import load_file, save_file
+    from tests.orbit_rank_worker import build, clip
+    from trajectorycrafter_amd.driver import ORBIT_VARIANTS, run_orbits
+    dev = torch.device("cuda:0")
+    pipe, warper = build(dev)
+    ckpt = tmp_path / "ckpt"
+    pipe.transformer.save_pretrained(str(ckpt / "transformer"))
+    pipe.vae.save_pretrained(str(ckpt / "vae"))
+    frames, depths, K, pe, ne = clip(dev)
+    clip_file = str(tmp_path / "clip.safetensors")
+    save_file({"frames": frames.cpu(), "depths": depths.cpu(), "K": K.cpu(), "prompt_embeds": pe.cpu(), "negative_prompt_embeds": ne.cpu()}, clip_file)
+    out = str(tmp_path / "orbits.safetensors")
+    r = _run(["orbits", "--model-dir", str(ckpt), "--clip", clip_file, "--out", out, "--variants", "right_30,left_-45", "--radius", "0.6",
+              "--steps", "2", "--height", "32", "--width", "48"])
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert json.loads(line["variants"]) == ["right_30", "left_-45"] and line["world_size"] == "1"
+    got = load_file(out)["frames"]
+    table = dict(ORBIT_VARIANTS)
+    want = run_orbits(pipe, warper, frames, depths, variants=(("right_30", table["right_30"]), ("left_-45", table["left_-45"])), radius=0.6, K=K,
+                      sample_size=(32, 48), prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=2, seed=43, mask=True)
+    assert got.shape == (2, 3, 9, 32, 48) and torch.equal(got, want.float().cpu())
+    bad = _run(["orbits", "--model-dir", str(ckpt), "--clip", clip_file, "--out", out, "--variants", "sideways"])
+    assert bad.returncode != 0 and "unknown variants" in bad.stderr
