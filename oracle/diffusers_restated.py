@@ -337,6 +337,14 @@ class DDIMScheduler:
         a_prev = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
         return a_t, a_prev
 
+    def add_noise(self, p: Prec, original_samples: torch.Tensor, noise: torch.Tensor, timestep: int) -> torch.Tensor:
+        """`DDIMScheduler.add_noise`: alphas_cumprod is cast to the sample dtype and all arithmetic runs in it (every op of the
+        eager bf16 execution rounds; in fp32 mode nothing does)."""
+        dt = p.act_dtype
+        abar = self.alphas_cumprod.to(dt)[int(timestep)]
+        sa, sb = abar ** 0.5, (1 - abar) ** 0.5
+        return (sa * original_samples.to(dt) + sb * noise.to(dt)).float()
+
     def step(self, p: Prec, model_output: torch.Tensor, timestep: int, sample: torch.Tensor, eta: float = 0.0):
         """`DDIMScheduler.step` (eta = 0).  `model_output` fp32, `sample` in the activation dtype.
 

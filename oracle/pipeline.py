@@ -90,8 +90,10 @@ def build_conditioning(vae_sd, vae_cfg, video, mask_video, reference, height, wi
 def denoise(tr_sd, tr_cfg, latents, prompt_embeds, negative_prompt_embeds, inpaint_latents, ref_input,
             height, width, num_inference_steps=50, guidance_scale=6.0, prec="fp32",
             scheduler: Optional[dr.DDIMScheduler] = None, num_blocks: Optional[int] = None,
-            on_step: Optional[Callable] = None):
-    """reference :1076-1198: the 50-step loop.  `latents` [B,T,16,h,w]; returns latents (activation dtype)."""
+            on_step: Optional[Callable] = None, strength: float = 1.0, video_latents: Optional[torch.Tensor] = None):
+    """reference :1076-1198: the 50-step loop.  `latents` [B,T,16,h,w]; returns latents (activation dtype).
+    strength < 1 (:664-671, :431-436): the loop starts `int(steps * strength)` steps before the end; when `video_latents`
+    is given, `latents` is the NOISE and the start point is scheduler.add_noise(video_latents, noise, first timestep)."""
     p = Prec(prec)
     sched = scheduler or dr.DDIMScheduler()
     do_cfg = guidance_scale > 1.0
@@ -100,8 +102,13 @@ def denoise(tr_sd, tr_cfg, latents, prompt_embeds, negative_prompt_embeds, inpai
     cfg = dict(otr.DEFAULT_CONFIG)
     cfg.update(tr_cfg)
     rotary = prepare_rotary(height, width, latents.shape[1], cfg["patch_size"], cfg["attention_head_dim"])
-    lat = p.R(latents * sched.init_noise_sigma)
-    for i, t in enumerate(sched.timesteps):
+    init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+    timesteps = sched.timesteps[max(num_inference_steps - init_timestep, 0):]
+    if strength < 1.0 and video_latents is not None:
+        lat = p.R(sched.add_noise(p, video_latents, latents, int(timesteps[0])))
+    else:
+        lat = p.R(latents * sched.init_noise_sigma)
+    for i, t in enumerate(timesteps):
         x = torch.cat([lat] * 2) if do_cfg else lat
         ts = t.expand(x.shape[0])
         noise_pred = otr.transformer_forward(tr_sd, cfg, x, pe, ts, inpaint_latents.float(), ref_input.float(),

@@ -14,6 +14,7 @@ from trajectorycrafter_amd.models.autoencoder_magvit import AutoencoderKLCogVide
 from trajectorycrafter_amd.models.crosstransformer3d import CrossTransformer3DModel, Timesteps
 from trajectorycrafter_amd.models.pipeline_trajectorycrafter import (TrajCrafter_Pipeline, get_3d_rotary_pos_embed,
                                                                     get_resize_crop_region_for_grid, resize_mask)
+from oracle.prec import Prec
 from trajectorycrafter_amd.scheduler import DDIMScheduler
 
 
@@ -82,6 +83,21 @@ def test_cog_scheduler_matches_oracle_and_sampler_table(tmp_path):
         init_noise_sigma = 1.0
     with pytest.raises(NotImplementedError, match="DDIM_Cog"):
         TrajCrafter_Pipeline(None, None, None, None, _Foreign())
+
+
+def test_scheduler_add_noise_matches_oracle_in_the_sample_dtype():
+    """`add_noise` of the `strength < 1` branch: schedule cast to the sample dtype, every op in it (CPU tensors here: torch glue)."""
+    from trajectorycrafter_amd.scheduler import CogVideoXDDIMScheduler
+    g = torch.Generator().manual_seed(3)
+    x0, nz = torch.randn(1, 3, 16, 4, 6, generator=g), torch.randn(1, 3, 16, 4, 6, generator=g)
+    for prod, orc in ((DDIMScheduler(), dr.DDIMScheduler()), (CogVideoXDDIMScheduler(), dr.CogVideoXDDIMScheduler())):
+        for t in (999, 499, 19):
+            for dt, mode in ((torch.bfloat16, "bf16"), (torch.float32, "fp32")):
+                got = prod.add_noise(x0.to(dt), nz.to(dt), torch.tensor([t]))
+                want = orc.add_noise(Prec(mode), x0.to(dt).float(), nz.to(dt).float(), t)
+                assert got.dtype == dt and torch.equal(got.float(), want), (type(prod).__name__, t, mode)
+    a = DDIMScheduler().add_noise(x0, nz, torch.tensor([999]))
+    torch.testing.assert_close(a, nz, rtol=0, atol=1e-6)                 # zero terminal SNR: pure noise at t = 999
 
 
 def test_run_cli_parses_the_reference_options():

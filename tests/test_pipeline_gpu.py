@@ -155,6 +155,52 @@ def test_pipeline_error_surface(setup):
                   num_inference_steps=1)
 
 
+def test_pipeline_strength_below_one_matches_oracle(setup):
+    """`strength < 1` (reference :664-671, :410-436): the loop starts `int(steps * strength)` steps before the end from the VAE-encoded
+    `video` noised to the first kept timestep (`scheduler.add_noise`, arithmetic in the latent dtype).  4 steps at strength 0.5 ->
+    the last 2 timesteps [499, 249].  Checked: the start latents against the oracle (same encoder sample: the product's own posterior
+    draw is reproduced through the global seed), the denoised latents against the oracle's bf16 contract / fp32 run (`_check_deep`),
+    `latents=` given -> plain noise start but still the shortened schedule, the argument surface."""
+    s, tp = setup, setup["tp"]
+    pipe, dev = s["pipe"], s["dev"]
+    kw = dict(prompt=None, height=32, width=48, num_frames=9, num_inference_steps=4, guidance_scale=6.0, strength=0.5,
+              prompt_embeds=tp["prompt_embeds"].to(BF), negative_prompt_embeds=tp["negative_prompt_embeds"].to(BF), video=tp["video"],
+              inpaint_latents=s["inpaint"].to(BF), ref_latents=s["ref"].to(BF))
+    g = lambda: torch.Generator(device=dev).manual_seed(43)
+    torch.manual_seed(9)
+    st = pipe.prepare_denoise(generator=g(), **{k: v for k, v in kw.items()})
+    assert st.timesteps == [499, 249] and st.num_inference_steps == 2
+    # the same start point from the pieces: encoder posterior sample (global RNG, same seed), noise (same generator), add_noise
+    torch.manual_seed(9)
+    init_video = pipe._preprocess(tp["video"].to(dev), 32, 48)
+    vl = (pipe.vae.encode(init_video.to(BF))[0].sample() * pipe.vae.config.scaling_factor).to(BF).permute(0, 2, 1, 3, 4)
+    noise = torch.randn(vl.shape, generator=g(), device=dev, dtype=BF)
+    from oracle import diffusers_restated as dr
+    from oracle.prec import Prec
+    osched = dr.DDIMScheduler()
+    osched.set_timesteps(4)
+    want0 = osched.add_noise(Prec("bf16"), vl.float().cpu(), noise.float().cpu(), 499)
+    assert torch.equal(st.latents.float().cpu(), want0.to(BF).float())          # the same bf16 arithmetic, bit for bit
+    torch.manual_seed(9)
+    lat = pipe(generator=g(), output_type="latent", **kw).videos
+    args = (s["wt"], s["tr_cfg"], noise.float().cpu(), tp["prompt_embeds"].to(BF).float(), tp["negative_prompt_embeds"].to(BF).float(),
+            s["inpaint"].to(BF).float(), s["ref"].to(BF).float(), 32, 48, 4, 6.0)
+    con = opl.denoise(*args, prec="bf16", strength=0.5, video_latents=vl.float().cpu())
+    ex = opl.denoise(*args, prec="fp32", strength=0.5, video_latents=vl.float().cpu())
+    _check_deep(lat, con, ex, "pipeline latents, strength 0.5 (2 of 4 steps from the noised video latents)")
+    # latents= given: noise * init_noise_sigma start (reference :443-445), shortened schedule all the same
+    lat2 = pipe(output_type="latent", latents=tp["latents0"].to(BF), **kw).videos
+    con2 = opl.denoise(s["wt"], s["tr_cfg"], tp["latents0"].to(BF).float(), *args[3:], prec="bf16", strength=0.5)
+    ex2 = opl.denoise(s["wt"], s["tr_cfg"], tp["latents0"].to(BF).float(), *args[3:], prec="fp32", strength=0.5)
+    _check_deep(lat2, con2, ex2, "pipeline latents, strength 0.5 with latents= given")
+    with pytest.raises(ValueError, match="strength"):
+        pipe(**dict(kw, strength=0.0))
+    with pytest.raises(ValueError, match="pass `video=`"):
+        pipe(**{k: v for k, v in kw.items() if k != "video"})
+    with pytest.raises(ValueError, match="eta"):
+        pipe(**dict(kw, eta=0.5))
+
+
 def test_conditioning_from_pixels_matches_oracle(setup):
     """reference :862-897, :927-1028 through the HIP VAE encoder: masked-video latents + resized mask (deterministic:
     `.mode()`), and the reference-frame posterior (mean / std; its `.sample()` draws from the device RNG)."""

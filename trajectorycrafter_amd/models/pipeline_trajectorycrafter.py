@@ -255,16 +255,26 @@ class TrajCrafter_Pipeline:
                                  f"{negative_prompt_embeds.shape}.")
 
     def prepare_latents(self, batch_size, num_channels_latents, height, width, video_length, dtype, device, generator,
-                        latents=None):
-        """reference :383-457 (strength == 1 branch: pure noise * init_noise_sigma)."""
+                        latents=None, video=None, timestep=None, is_strength_max=True):
+        """reference :383-457.  strength == 1: pure noise * init_noise_sigma; strength < 1 (and no `latents=`): the VAE-encoded
+        (posterior SAMPLE, global RNG, x scaling_factor) preprocessed `video` noised to the first timestep of the shortened loop
+        (`scheduler.add_noise`, :431-436).  -> (latents, noise)."""
         shape = (batch_size, (video_length - 1) // self.vae_scale_factor_temporal + 1, num_channels_latents,
                  height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial)
         if isinstance(generator, list) and len(generator) != batch_size:
             raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective "
                              f"batch size of {batch_size}.")
         if latents is None:
+            video_latents = None
+            if not is_strength_max:
+                if video is None:
+                    raise ValueError("`strength` < 1 starts from the encoded `video`: pass `video=` (or `latents=`)")
+                vl = self.vae.encode(video.to(device=device, dtype=dtype))[0].sample() * self.vae.config.scaling_factor   # :410-421
+                video_latents = vl.repeat(batch_size // vl.shape[0], 1, 1, 1, 1).to(dtype).permute(0, 2, 1, 3, 4)
             gdev = generator.device if generator is not None else device
             noise = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)     # randn_tensor
+            if video_latents is not None:
+                return self.scheduler.add_noise(video_latents, noise, timestep).to(dtype), noise     # :431-436, no init sigma (:438-442)
         else:
             if tuple(latents.shape) != shape:
                 raise ValueError(f"`latents` has shape {tuple(latents.shape)}, expected {shape}")
@@ -438,8 +448,10 @@ class TrajCrafter_Pipeline:
         if num_frames > 49:
             raise ValueError("The number of frames must be less than 49 for now due to static positional embeddings. "
                              "This will be updated in the future to remove this limitation.")
-        if eta != 0.0 or strength != 1:
-            raise ValueError("only eta = 0 and strength = 1 (the reference's inference settings) are implemented")
+        if eta != 0.0:
+            raise ValueError("only eta = 0 (deterministic DDIM, the reference's inference setting) is implemented")
+        if not 0.0 < strength <= 1.0:
+            raise ValueError(f"`strength` must be in (0, 1], got {strength}")
         num_videos_per_prompt = 1
         self.check_inputs(prompt, height, width, negative_prompt, list(callback_on_step_end_tensor_inputs), prompt_embeds,
                           negative_prompt_embeds)
@@ -486,8 +498,12 @@ class TrajCrafter_Pipeline:
         if ref_input.shape[0] == batch_size and rep == 2:
             ref_input = torch.cat([ref_input] * 2)
         num_channels_latents = self.vae.config.latent_channels
+        init_video = None
+        if strength != 1 and latents is None and video is not None:
+            init_video = self._preprocess(video.to(device), height, width)                              # :863-871
         latents, _ = self.prepare_latents(batch_size * num_videos_per_prompt, num_channels_latents, height, width,
-                                          video_length, BF16, device, generator, latents)
+                                          video_length, BF16, device, generator, latents, video=init_video,
+                                          timestep=timesteps[:1], is_strength_max=strength == 1)
         latents = latents.contiguous()
         if inpaint_latents.shape[:2] != (rep * batch_size, latents.shape[1]) or inpaint_latents.shape[3:] != latents.shape[3:]:
             raise ValueError(f"inpaint_latents {tuple(inpaint_latents.shape)} does not match latents {tuple(latents.shape)}")

@@ -83,6 +83,18 @@ class DDIMScheduler:
         a_prev = float(self.alphas_cumprod[prev]) if prev >= 0 else float(self.final_alpha_cumprod)
         return a_t, a_prev
 
+    def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timesteps) -> torch.Tensor:
+        """diffusers `DDIMScheduler.add_noise` (used by the reference's `strength < 1` branch, pipeline :431-436): the schedule is
+        cast to the SAMPLE dtype first and every operation runs in it — sqrt(abar_t) x0 + sqrt(1 - abar_t) noise with bf16
+        intermediates for bf16 latents.  Torch elementwise ops on the latent tensor, once per clip (conditioning preparation)."""
+        abar = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
+        t = torch.as_tensor(timesteps, device=original_samples.device).reshape(-1).long()
+        sa = abar[t] ** 0.5
+        sb = (1 - abar[t]) ** 0.5
+        while sa.dim() < original_samples.dim():
+            sa, sb = sa.unsqueeze(-1), sb.unsqueeze(-1)
+        return sa * original_samples + sb * noise
+
     def fused_cfg_step(self, uncond: torch.Tensor, cond: Optional[torch.Tensor], sample: torch.Tensor, guidance: float,
                        timestep: int) -> torch.Tensor:
         """CFG combine (pipeline :1157-1161) + `step` + the bf16 cast (:1178) as ONE kernel (`tcx_cfg_ddim_step`)."""
