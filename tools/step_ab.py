@@ -1,6 +1,7 @@
 """In-process A/B of a module-level switch on the FULL denoising step (the bench's step: 42-layer model at 49f 480x720, CFG batch 2):
 alternating blocks of steps with the switch off / on, so that both arms see the same box, clock history and data.
-usage: python tools/step_ab.py [steps_per_block] [blocks]      (switch: ops.ATTN_BODY16_DEFAULT)"""
+usage: python tools/step_ab.py [steps_per_block] [blocks] [switch]      switch: body16 (ops.ATTN_BODY16_DEFAULT, default) | cross_kv
+(model.cache_cross_kv: reuse of the cross-attention K / V across steps)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,6 +11,7 @@ from trajectorycrafter_amd import ops
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+switch = sys.argv[3] if len(sys.argv) > 3 else "body16"
 args = bench.parse([])
 dev = torch.device("cuda:0")
 pipe = bench.build_models(args, dev)
@@ -28,9 +30,14 @@ steps(2)
 res = {False: [], True: []}
 for b in range(blocks):
     for flag in (False, True):
-        ops.ATTN_BODY16_DEFAULT = flag
+        if switch == "body16":
+            ops.ATTN_BODY16_DEFAULT = flag
+        else:
+            pipe.transformer.cache_cross_kv = flag
+            if flag:
+                steps(1)                                   # fill the cache outside the timed block
         ms, att = steps(n)
         res[flag].append((ms, att))
-        print(f"block {b} body16={flag}: {ms:.1f} ms per step, self-attention {att:.3f} ms per launch", flush=True)
+        print(f"block {b} {switch}={flag}: {ms:.1f} ms per step, self-attention {att:.3f} ms per launch", flush=True)
 for flag in (False, True):
-    print(f"body16={flag}: median step {sorted(x[0] for x in res[flag])[len(res[flag]) // 2]:.1f} ms, attention {sorted(x[1] for x in res[flag])[len(res[flag]) // 2]:.3f} ms")
+    print(f"{switch}={flag}: median step {sorted(x[0] for x in res[flag])[len(res[flag]) // 2]:.1f} ms, attention {sorted(x[1] for x in res[flag])[len(res[flag]) // 2]:.3f} ms")
