@@ -17,7 +17,8 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"gpurun_out/{tag}_pmc_attn_{ctr}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == ctr and ("attn_fwd" in r["Kernel_Name"] or "attn_combine" in r["Kernel_Name"]):
-                per[r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "")][ctr].append(float(r["Counter_Value"]))
+                n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+                per[n[:n.index("(")] if "(" in n else n][ctr].append(float(r["Counter_Value"]))
 out = {"collection": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes, no trace domains, tools/attn_body_bench.py 2 1 ([2,17776,48,64], product flags)",
        "gfx950_correction": "read bytes = 2 x FETCH_SIZE x 1024 (128-B requests tallied at 64 B); WRITE_SIZE exact for 16-B-per-lane stores",
        "algorithmic_bytes_per_launch": 4 * 2 * 17776 * 48 * 64 * 2, "kernels": {}}
