@@ -22,11 +22,13 @@ def t(body16):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 for _ in range(2):
-    t(True); t(False)
-res = {True: [], False: []}
+    t(True); t(False); t(4)
+res = {True: [], False: [], 4: []}
 for rep in range(rounds):
-    a, b = t(False), t(True)
-    res[False].append(a); res[True].append(b)
-    print(f"32x32x16 body {a:.3f} ms ({flop / a / 1e9:.0f} TF)   16x16x32 body {b:.3f} ms ({flop / b / 1e9:.0f} TF)   16 vs 32: {100 * (a - b) / a:+.2f} %", flush=True)
+    a, b, c = t(False), t(True), t(4)
+    res[False].append(a); res[True].append(b); res[4].append(c)
+    print(f"32x32x16 body {a:.3f} ms ({flop / a / 1e9:.0f} TF)   16x16x32 body {b:.3f} ms ({flop / b / 1e9:.0f} TF)   4-wave body {c:.3f} ms ({flop / c / 1e9:.0f} TF)   "
+          f"4-wave vs 32: {100 * (a - c) / a:+.2f} %", flush=True)
 med = lambda x: sorted(x)[len(x) // 2]
-print(f"median: 32x32x16 {med(res[False]):.3f} ms = {flop / med(res[False]) / 1e9:.0f} TF | 16x16x32 {med(res[True]):.3f} ms = {flop / med(res[True]) / 1e9:.0f} TF")
+print(f"median: 32x32x16 {med(res[False]):.3f} ms = {flop / med(res[False]) / 1e9:.0f} TF | 16x16x32 {med(res[True]):.3f} ms = {flop / med(res[True]) / 1e9:.0f} TF"
+      f" | 4-wave {med(res[4]):.3f} ms = {flop / med(res[4]) / 1e9:.0f} TF")

@@ -1,0 +1,20 @@
+# cycles + clock of the attention main loops, stand-alone (tools/attn_body_bench.py under a -DTCX_ATTN_STAMP build)
+R=$GRAFT_REPO_ROOT
+cd $R/trajectorycrafter_amd/csrc
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -w -I. -DTCX_ATTN_STAMP $1 -x hip -c attn_fwd.hip -o /tmp/attn_clk.o || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libtcx_aclk.so tcx_api.o /tmp/attn_clk.o norm.o elementwise.o conv.o conv_mfma.o groupnorm.o warp.o gemm.o || exit 1
+cd $R
+TCX_LIB=/tmp/libtcx_aclk.so python3 tools/attn_body_bench.py ${2:-25} ${3:-4} > gpurun_out/attn_stamps.log 2>&1
+grep -v ASTAMP gpurun_out/attn_stamps.log | tail -3
+python3 - <<'PY'
+import re, statistics
+by = {}
+for l in open("gpurun_out/attn_stamps.log"):
+    m = re.match(r"ASTAMP body (\d+) D (\d+) wg \d+ wave (\d+) tiles (\d+) cycles (\d+) real (\d+)", l)
+    if m and int(m.group(4)) > 200:
+        by.setdefault((m.group(1), m.group(3)), []).append((int(m.group(5)), int(m.group(6))))
+for k, v in sorted(by.items()):
+    v = v[len(v) // 2:]
+    print("body", k[0], "wave", k[1], "stamps", len(v), "median cycles", statistics.median(c for c, _ in v), "per tile", round(statistics.median(c for c, _ in v) / 278),
+          "median us", statistics.median(r for _, r in v) / 100, "clock GHz", round(statistics.median(c / r * 0.1 for c, r in v), 3))
+PY

@@ -8,7 +8,7 @@ k=torch.randn(B,S,H,D,device='cuda',dtype=torch.bfloat16,generator=g); v=torch.r
 ksq=(k.float()**2).sum(-1).amax(1).contiguous()
 a=ops.attn_fwd(q,k,v,1.0,log2_scores=True,k_sqmax=ksq,bound_proven=True,body16=False)
 b=ops.attn_fwd(q,k,v,1.0,log2_scores=True,k_sqmax=ksq,bound_proven=True,body16=True)
-c=ops.attn_fwd(q,k,v,1.0,log2_scores=True,k_sqmax=ksq,bound_proven=True,body16=2)
+c=ops.attn_fwd(q,k,v,1.0,log2_scores=True,k_sqmax=ksq,bound_proven=True,body16=4)
 s=q.float().transpose(1,2)@k.float().transpose(1,2).transpose(-1,-2)
 ref=(torch.softmax(s*math.log(2),-1)@v.float().transpose(1,2)).transpose(1,2)
-for n,x in (('32',a),('16',b),('16+summ',c)): print(n, float((x.float()-ref).abs().max()), float((x.float()-ref).abs().mean()))
+for n,x in (('32',a),('16',b),('4-wave',c)): print(n, float((x.float()-ref).abs().max()), float((x.float()-ref).abs().mean()))

@@ -16,6 +16,7 @@ TCX_BF16, TCX_F32 = 0, 1
 TCX_ATTN_LOG2_SCORES = 1
 TCX_ATTN_BOUND_PROVEN = 2
 TCX_ATTN_BODY_16X16X32 = 4
+TCX_ATTN_BODY_4WAVE = 8
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 

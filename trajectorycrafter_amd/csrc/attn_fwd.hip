@@ -1085,6 +1085,436 @@ __global__ __launch_bounds__(512) void attn_fwd16_kernel(const AttnParams p) {
     }
 }
 
+// ---- 4 waves x 64 query rows: one wave per SIMD, the whole 512-entry register file (round 3) ---------------------------------------
+// Why: the 8-wave loop is bound by the SIMD's instruction issue (2 waves x ~840 issue cycles per tile); its fragment reads, waits and
+// staging are paid once per 32 query rows.  Here a wave owns TWO 32-row query blocks (A, B) that share every K / V fragment read and
+// every staging instruction, the row sums go to the matrix pipe (ones . P^T), and nothing is centred (|S| <= M < 60 is guaranteed by
+// TCX_ATTN_BOUND_PROVEN, so P = exp2(S) cannot overflow and the scale cancels in O / l): per 64-key tile a wave issues 40 MFMA
+// (1280 matrix-pipe cycles) beside 64 v_exp_f32 + 32 v_cvt_pk + 24 LDS reads (~1200 issue cycles) instead of 2 x 840.
+// Register plan (hipcc picks ONE register form per MFMA builtin per function, so the MFMAs are inline asm with explicit classes):
+// S tiles of both blocks (exp inputs) in arch VGPRs, O / row-sum accumulators and the Q fragments in AGPRs, never copied in the loop.
+// Hazards the asm statements hide from hipcc (cdna_hip_programming.md 5.7) are kept away by construction: P is converted one slot
+// (5 MFMAs) before the MFMA that reads it, K / V fragments arrive by counted LDS reads, S tiles are exponentiated >= 5 MFMAs after
+// the last MFMA that wrote them, the epilogue waits out the last MFMA explicitly.
+namespace mf {
+__device__ __forceinline__ void s_first(f32x16& d, const bf16x8& k, const bf16x8& q) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+}
+__device__ __forceinline__ void s_acc(f32x16& d, const bf16x8& k, const bf16x8& q) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+}
+__device__ __forceinline__ void o_acc(f32x16& acc, const bf16x8& a, const bf16x8& pfrag) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(pfrag));
+}
+__device__ __forceinline__ void o_acc_nop(f32x16& acc, const bf16x8& a, const bf16x8& pfrag) {       // pfrag may have been written by the
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(pfrag));   // VALU instruction just before
+}
+__device__ __forceinline__ void l_acc(f32x16& acc, const bf16x8& ones_a, const bf16x8& pfrag) {     // A operand (all ones) in AGPRs
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(ones_a), "v"(pfrag));
+}
+}  // namespace mf
+
+__global__ __launch_bounds__(256) void attn_fwd4_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int D = 64, TILEB = 64 * D * 2, TPB = 2, R = 6, NLD = 2;     // R = 6: see the ring note at super_step
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    uint32_t pb = blockIdx.x;
+    int part = -1;
+    uint32_t item = 0;
+    if (p.split > 1 && pb >= p.n_full) {
+        item = pb - p.n_full;
+        part = (int)(item % p.split);
+        pb = p.n_full + item / p.split;
+    }
+    const uint32_t id = xcd_remap(pb, p.nwg);
+    const uint32_t bh = id / p.nqb, qb_ = id - bh * p.nqb;
+    const int b = bh / p.H, hd = bh - b * p.H;
+    const int q0 = qb_ * 256 + wave * 64;                  // this wave: rows q0 .. q0 + 63 = blocks A (q0 ..) and B (q0 + 32 ..)
+
+    const uint16_t* kbase = p.k + (int64_t)b * p.ksb + (int64_t)hd * p.ksh;
+    const uint16_t* vbase = p.v + (int64_t)b * p.vsb + (int64_t)hd * p.vsh;
+    int Sk = p.Sk;
+    if (part >= 0) {
+        const int T = (p.Sk + 63) >> 6;
+        const int t_lo = (int)((int64_t)part * T / p.split), t_hi = (int)((int64_t)(part + 1) * T / p.split);
+        kbase += (int64_t)t_lo * 64 * p.kss;
+        vbase += (int64_t)t_lo * 64 * p.vss;
+        Sk = min(p.Sk, t_hi * 64) - t_lo * 64;
+    }
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)((((int64_t)Sk - 1) * p.kss + D) * 2), 0x00020000);
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)((((int64_t)Sk - 1) * p.vss + D) * 2), 0x00020000);
+    const int ktile_bytes = (int)(64 * p.kss * 2), vtile_bytes = (int)(64 * p.vss * 2);
+    const int ntiles = (Sk + 63) >> 6;
+    if (part >= 0 && tid == 0)
+        reinterpret_cast<uint32_t*>(p.ws + attn_ws_o_floats(p.split * (p.nwg - p.n_full), D) + (size_t)p.split * (p.nwg - p.n_full) * 256)[item] = 1u;
+
+    // ---- Q fragments (B operand of QK^T, AGPRs): lane holds Q[q0 + 32 blk + r][16 ks + 8 h .. + 8] ----
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        int qrow = q0 + 32 * blk + r;
+        if (qrow >= p.Sq) qrow = p.Sq - 1;
+        const uint16_t* qp = p.q + (int64_t)b * p.qsb + (int64_t)qrow * p.qss + (int64_t)hd * p.qsh + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[blk][ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+
+    // ---- staging: global -> registers -> LDS (issue early / write late), 2 x 16 bytes per thread per operand and tile ----
+    int kvoff[NLD], vvoff[NLD], klds[NLD], vlds[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx >> 3, ch = idx & 7;
+        kvoff[i] = (int)(row * p.kss * 2) + ch * 16;
+        vvoff[i] = (int)(row * p.vss * 2) + ch * 16;
+        klds[i] = k_off<64>(row, ch);
+        vlds[i] = v_chunk_off<64>(row, ch);
+    }
+    u32x4 kreg[TPB][NLD], vreg[TPB][NLD];
+    auto load_k = [&](auto jc, int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) kreg[decltype(jc)::value][i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[i] + tile * ktile_bytes, 0, 0);
+    };
+    auto load_v = [&](auto jc, int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) vreg[decltype(jc)::value][i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[i] + tile * vtile_bytes, 0, 0);
+    };
+    char* const kbuf0 = smem;
+    char* const vbuf0 = smem + R * TILEB;
+    auto write_k = [&](auto jc, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(kbuf0 + slot * TILEB + klds[i]) = kreg[decltype(jc)::value][i];
+    };
+    auto write_v = [&](auto jc, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(vbuf0 + slot * TILEB + vlds[i]) = vreg[decltype(jc)::value][i];
+    };
+
+    // ---- LDS read bases (the images and fragment addressing of attn_fwd_kernel<64>) ----
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = k_off<64>(r, 2 * ks + h);
+    constexpr int K_T_STRIDE = 32 * D * 2;
+    const int gl = lane & 15, q4 = gl >> 2, pp = gl & 3, g = (lane >> 4) & 1;
+    int voff[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int dcol = 32 * dt + 16 * g + 4 * pp;
+        voff[dt] = v_chunk_off<64>(4 * h + q4, dcol >> 3) + ((dcol & 7) << 1);
+    }
+    auto read_k = [&](const char* kb, int ks, bf16x8 (&kf)[2]) __attribute__((always_inline)) {
+#ifdef TCX_A4_NOLDS
+        if (ntiles > 0) return;
+#endif
+#pragma unroll
+        for (int t = 0; t < 2; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(kb + koff[ks] + t * K_T_STRIDE);
+    };
+    auto read_v = [&](const char* vb, int st, bf16x8 (&vf)[2]) __attribute__((always_inline)) {
+#ifdef TCX_A4_NOLDS
+        if (ntiles > 0) return;
+#endif
+        const int rowb = (32 * (st >> 1) + 16 * (st & 1)) * (D * 2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            auto p0 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + rowb);
+            auto p1 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + rowb + 8 * (D * 2));
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p1);
+            vf[dt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+
+    f32x16 o[2][2], lacc[2];                               // AGPRs: O^T[blk][dt], row sums
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[blk][0][i] = o[blk][1][i] = lacc[blk][i] = 0.f;
+    }
+    f32x16 sa[2][2], sb[2][2];                             // VGPRs: S^T of the current / next tile, [blk][t]
+    bf16x8 ones, pprev, kfa[2], kfb[2], vfa[2], vfb[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ones[j] = (__bf16)1.0f; pprev[j] = (__bf16)0.0f; }
+    asm volatile("" : "+a"(ones));                          // opaque + resident in AGPRs: never re-materialised next to an asm MFMA
+    vfa[0] = vfa[1] = vfb[0] = vfb[1] = pprev;
+
+    auto mask_tail = [&](f32x16 (&s)[2][2]) {              // keys >= Sk of the last tile
+        const int kv0 = (ntiles - 1) * 64 + 4 * h;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (kv0 + 32 * t + (i & 3) + 8 * (i >> 2) >= Sk) s[blk][t][i] = -INFINITY;
+    };
+
+    // One slot (ST, BLK): exponentials of cur[BLK] for the 16 keys of step ST | the two QK^T MFMAs nxt[BLK][0..1] of k-step ST | PV +
+    // row-sum MFMAs of the PREVIOUS slot's P (its V fragments: vp).  5 MFMAs, 8 exp, 4 cvt.  One wave per SIMD: nothing hides a
+    // dependency stall, so (a) every v_cvt_pk packs the exponentials of the PREVIOUS gap (the transcendental's latency passes under
+    // an MFMA issue), (b) the P operand finished by the last convert of a slot is first read two MFMAs into the next slot (QK^T
+    // first) — except in slot (0, A), whose K fragments were only just requested: it runs P first behind an explicit s_nop 1 (the
+    // VALU -> MFMA-operand wait states hipcc cannot add around an asm statement).
+    auto slot = [&](auto has_next, auto stc, auto blkc, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], bf16x8 (&kf)[2], bf16x8 (&vp)[2])
+        __attribute__((always_inline)) {
+        constexpr bool NEXT = decltype(has_next)::value;
+        constexpr int ST = decltype(stc)::value, BLK = decltype(blkc)::value, QP = 1 - BLK;
+        constexpr int T = ST >> 1, S2 = ST & 1;
+        constexpr bool PFIRST = ST == 0 && BLK == 0;
+        u32x4 pw;
+        float e[8];
+#ifdef TCX_A4_NOEXP                    // timing-only ablations (wrong results): what each instruction class costs the single wave
+        auto ex = [&](int j) __attribute__((always_inline)) { e[j] = cur[BLK][T][8 * S2 + j]; asm volatile("" : "+v"(e[j])); };
+#else
+        auto ex = [&](int j) __attribute__((always_inline)) { e[j] = __builtin_amdgcn_exp2f(cur[BLK][T][8 * S2 + j]); };
+#endif
+        auto cv = [&](int j) __attribute__((always_inline)) {      // pack e[j], e[j + 1] here, in this gap
+            uint32_t w = pack_bf16(e[j], e[j + 1]);
+            asm volatile("" : "+v"(w));
+            pw[j >> 1] = w;
+        };
+        auto qk = [&](int t) __attribute__((always_inline)) {
+            if constexpr (NEXT) {
+                if constexpr (ST == 0) mf::s_first(nxt[BLK][t], kf[t], qf[BLK][ST]);
+                else mf::s_acc(nxt[BLK][t], kf[t], qf[BLK][ST]);
+            }
+        };
+        auto pv = [&](int which) __attribute__((always_inline)) {
+            if (which == 0) {
+                if constexpr (PFIRST) mf::o_acc_nop(o[QP][0], vp[0], pprev);
+                else mf::o_acc(o[QP][0], vp[0], pprev);
+            } else if (which == 1) mf::o_acc(o[QP][1], vp[1], pprev);
+            else {
+#ifndef TCX_A4_NOSUM
+                mf::l_acc(lacc[QP], ones, pprev);
+#endif
+            }
+        };
+        auto mm = [&](int gap) __attribute__((always_inline)) {    // the MFMA of gap 0..4
+            if constexpr (PFIRST) { if (gap < 3) pv(gap); else qk(gap - 3); }
+            else { if (gap < 2) qk(gap); else pv(gap - 2); }
+        };
+        mm(0); ex(0); ex(1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1); ex(2); ex(3); cv(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(2); ex(4); ex(5); cv(2);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(3); ex(6); ex(7); cv(4);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(4); cv(6);
+        __builtin_amdgcn_sched_barrier(0);
+        pprev = __builtin_bit_cast(bf16x8, pw);
+    };
+    // A tile: slots (0,A) (0,B) (1,A) ... (3,B).  V fragments of step ST (shared by both blocks) are read at the start of slot (ST, A)
+    // and used by slots (ST, B) and (ST + 1, A); K fragments of k-step ST + 1 are read at the start of slot (ST, B).  The fragments of
+    // slot (0, A) — K k-step 0 of the tile's K slot into kfa, V step 0 into vfa — are requested by whoever runs BEFORE the tile (the
+    // previous tile's end, ahead of the barrier: `prefetch`), so that a tile never opens with an LDS round trip.  `mid` is called
+    // after slots (0,B) (1,B) (2,B) (3,A) of the tile: the hook where the second tile of a super-step writes the staged tiles to LDS.
+    auto prefetch = [&](const char* kb, const char* vb, bool with_k) __attribute__((always_inline)) {
+        if (with_k) read_k(kb, 0, kfa);
+        read_v(vb, 0, vfa);
+    };
+    auto tile = [&](auto has_next, const char* kb, const char* vb, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], auto&& mid) __attribute__((always_inline)) {
+        constexpr bool NEXT = decltype(has_next)::value;
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        slot(has_next, I0{}, I0{}, cur, nxt, kfa, vfb);          // (0,A): P of the previous tile's (3,B), V of its step 3 (vfb)
+        if constexpr (NEXT) read_k(kb, 1, kfb);
+        slot(has_next, I0{}, I1{}, cur, nxt, kfa, vfa);          // (0,B): P of (0,A), V of step 0
+        mid(I0{});
+        read_v(vb, 1, vfb);
+        slot(has_next, I1{}, I0{}, cur, nxt, kfb, vfa);          // (1,A): P of (0,B), V of step 0
+        if constexpr (NEXT) read_k(kb, 2, kfa);
+        slot(has_next, I1{}, I1{}, cur, nxt, kfb, vfb);          // (1,B): P of (1,A), V of step 1
+        mid(I1{});
+        read_v(vb, 2, vfa);
+        slot(has_next, I2{}, I0{}, cur, nxt, kfa, vfb);          // (2,A)
+        if constexpr (NEXT) read_k(kb, 3, kfb);
+        slot(has_next, I2{}, I1{}, cur, nxt, kfa, vfa);          // (2,B)
+        mid(I2{});
+        read_v(vb, 3, vfb);
+        slot(has_next, I3{}, I0{}, cur, nxt, kfb, vfa);          // (3,A)
+        mid(I3{});
+        slot(has_next, I3{}, I1{}, cur, nxt, kfb, vfb);          // (3,B)
+    };
+    auto no_mid = [](auto) {};
+
+    constexpr std::integral_constant<int, 0> J0{};
+    constexpr std::integral_constant<int, 1> J1{};
+    // Ring of R = 6 slots per operand, tile t in slot t % 6; a super-step = tiles t0, t0 + 1 (PH = t0 % 6), ONE barrier.  With one wave
+    // per SIMD nothing overlaps a barrier, so nothing may WAIT at it (ablation, tools/exp/attn4_ablate.sh: with R = 4 — tiles staged
+    // in super-step s are read in s + 1 — the ds_write burst, its lgkmcnt(0), the barrier and the cold fragment pipeline behind it cost
+    // 471 of 1836 cycles per tile).  Here the tiles loaded at the top of super-step s (K[t0+5], K[t0+6], V[t0+4], V[t0+5]) are written
+    // during its SECOND tile, between slots, into slots last read in s - 1, and first read in s + 2: the barrier ending s only has
+    // to order them before s + 2 (the barrier ending s + 1 would do), the next tile's first fragments are requested before it, and the
+    // waves arrive with nothing pending.
+    auto super_step = [&](auto masked, auto ph, int t0) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph)::value;
+#if !defined(TCX_A4_NOSTAGE) && !defined(TCX_A4_NOLOADS)
+        load_k(J0, t0 + 5);
+        load_v(J0, t0 + 4);
+        load_k(J1, t0 + 6);
+        load_v(J1, t0 + 5);
+#endif
+        tile(std::true_type{}, kbuf0 + ((PH + 1) % R) * TILEB, vbuf0 + (PH % R) * TILEB, sa, sb, no_mid);
+        if constexpr (decltype(masked)::value) {
+            if (t0 + 1 == ntiles - 1 && (Sk & 63)) mask_tail(sb);
+        }
+        prefetch(kbuf0 + ((PH + 2) % R) * TILEB, vbuf0 + ((PH + 1) % R) * TILEB, true);
+        __builtin_amdgcn_sched_barrier(0);
+        tile(std::true_type{}, kbuf0 + ((PH + 2) % R) * TILEB, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa, [&](auto which) __attribute__((always_inline)) {
+#if !defined(TCX_A4_NOSTAGE) && !defined(TCX_A4_NOWRITES)
+            constexpr int W = decltype(which)::value;
+            if constexpr (W == 0) write_k(J0, (PH + 5) % R);
+            if constexpr (W == 1) write_v(J0, (PH + 4) % R);
+            if constexpr (W == 2) write_k(J1, (PH + 6) % R);
+            if constexpr (W == 3) write_v(J1, (PH + 5) % R);
+#endif
+        });
+        if constexpr (decltype(masked)::value) {
+            if (t0 + 2 == ntiles - 1 && (Sk & 63)) mask_tail(sa);
+        }
+        prefetch(kbuf0 + ((PH + 3) % R) * TILEB, vbuf0 + ((PH + 2) % R) * TILEB, true);     // tile t0 + 2: resident since the previous barrier
+        __builtin_amdgcn_sched_barrier(0);
+#if !defined(TCX_A4_NOSTAGE) && !defined(TCX_A4_NOBAR)
+        __syncthreads();
+#endif
+    };
+    // the last 1 or 2 tiles (everything they read is resident; nothing is staged)
+    auto tail = [&](auto ph, int t0) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph)::value;
+        if ((ntiles - 1) - t0 == 1) {
+            tile(std::true_type{}, kbuf0 + ((PH + 1) % R) * TILEB, vbuf0 + (PH % R) * TILEB, sa, sb, no_mid);
+            if (Sk & 63) mask_tail(sb);
+            prefetch(nullptr, vbuf0 + ((PH + 1) % R) * TILEB, false);
+            tile(std::false_type{}, nullptr, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa, no_mid);
+        } else {
+            tile(std::false_type{}, nullptr, vbuf0 + (PH % R) * TILEB, sa, sb, no_mid);
+        }
+    };
+
+    // prologue: K[0 .. 4], V[0 .. 3] into their slots, S(0) of both blocks, the first tile's fragments
+    load_k(J0, 0); load_v(J0, 0); load_k(J1, 1); load_v(J1, 1);
+    write_k(J0, 0); write_v(J0, 0); write_k(J1, 1); write_v(J1, 1);
+    load_k(J0, 2); load_v(J0, 2); load_k(J1, 3); load_v(J1, 3);
+    write_k(J0, 2); write_v(J0, 2); write_k(J1, 3); write_v(J1, 3);
+    load_k(J0, 4);
+    write_k(J0, 4);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        read_k(kbuf0, ks, kfb);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (ks == 0) mf::s_first(sa[blk][t], kfb[t], qf[blk][ks]);
+                else mf::s_acc(sa[blk][t], kfb[t], qf[blk][ks]);
+            }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last QK^T MFMA has written S before anything reads it
+    if (ntiles == 1 && (Sk & 63)) mask_tail(sa);
+    prefetch(kbuf0 + 1 * TILEB, vbuf0, ntiles > 1);
+    __syncthreads();                                        // K slot 0 is written again during the first super-step
+
+#ifdef TCX_ATTN_STAMP
+    const unsigned long long tC0 = __builtin_amdgcn_s_memtime(), tR0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+    {
+        using P0 = std::integral_constant<int, 0>; using P2 = std::integral_constant<int, 2>; using P4 = std::integral_constant<int, 4>;
+        const std::false_type plain{};
+        const std::true_type masked{};
+        int t0 = 0;
+        // steady state, three super-steps (one turn of the ring) per iteration: a super-step computes the scores up to tile t0 + 2; while
+        // that is not the last tile there is no mask code
+        for (; t0 + 6 < ntiles - 1; t0 += 6) {
+            super_step(plain, P0{}, t0);
+            super_step(plain, P2{}, t0 + 2);
+            super_step(plain, P4{}, t0 + 4);
+        }
+        // remainder: 0..2 plain super-steps, at most one that reaches the last tile exactly (masked), then the last 1 or 2 tiles
+        if (t0 + 2 < ntiles - 1) {
+            super_step(plain, P0{}, t0);
+            t0 += 2;
+            if (t0 + 2 < ntiles - 1) {
+                super_step(plain, P2{}, t0);
+                t0 += 2;
+                if (t0 + 2 <= ntiles - 1) { super_step(masked, P4{}, t0); tail(P0{}, t0 + 2); }
+                else tail(P4{}, t0);
+            } else {
+                if (t0 + 2 <= ntiles - 1) { super_step(masked, P2{}, t0); tail(P4{}, t0 + 2); }
+                else tail(P2{}, t0);
+            }
+        } else {
+            if (t0 + 2 <= ntiles - 1) { super_step(masked, P0{}, t0); tail(P2{}, t0 + 2); }
+            else tail(P0{}, t0);
+        }
+    }
+#ifdef TCX_ATTN_STAMP
+    {
+        const unsigned long long tC1 = __builtin_amdgcn_s_memtime(), tR1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if ((blockIdx.x % 997 == 5) && lane == 0 && (wave == 0 || wave == 3))
+            printf("ASTAMP body 4 D 64 wg %d wave %d tiles %d cycles %llu real %llu\n", (int)blockIdx.x, wave, ntiles, tC1 - tC0, tR1 - tR0);
+    }
+#endif
+    // the delayed PV / row-sum product of the very last slot (3, B): V of step 3 = vfb
+    mf::o_acc_nop(o[1][0], vfb[0], pprev);
+    mf::o_acc(o[1][1], vfb[1], pprev);
+    mf::l_acc(lacc[1], ones, pprev);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // let the last MFMA retire before the accumulators are read
+
+    // ---- epilogue ----
+    float l[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) l[blk] = lacc[blk][0];   // every row of ones . P^T holds the row sums (both half-waves' keys)
+    if (part >= 0) {
+        const uint32_t items = p.split * (p.nwg - p.n_full);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            float* wo = p.ws + ((size_t)item * 256 + wave * 64 + 32 * blk + r) * D;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<f32x4*>(wo + 32 * dt + 8 * i + 4 * h) = f32x4{o[blk][dt][4 * i], o[blk][dt][4 * i + 1], o[blk][dt][4 * i + 2], o[blk][dt][4 * i + 3]};
+            if (h == 0) p.ws[attn_ws_o_floats(items, D) + (size_t)item * 256 + wave * 64 + 32 * blk + r] = l[blk];
+        }
+        return;
+    }
+    constexpr int RB = D * 2;
+    __syncthreads();                                       // every wave is past its last K / V fragment read
+    char* ot = smem + wave * (64 * RB);                    // 64 rows x 128 B; 16-byte chunk c of row q at c ^ (q & 7)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const float inv = 1.0f / l[blk];
+        const int row = 32 * blk + r;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d0 = 32 * dt + 8 * i + 4 * h;
+                u32x2 w;
+                w[0] = pack_bf16(o[blk][dt][4 * i] * inv, o[blk][dt][4 * i + 1] * inv);
+                w[1] = pack_bf16(o[blk][dt][4 * i + 2] * inv, o[blk][dt][4 * i + 3] * inv);
+                *reinterpret_cast<u32x2*>(ot + row * RB + (((d0 >> 3) ^ (row & 7)) << 4) + ((d0 & 4) << 1)) = w;
+            }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int rl = lane >> 3, ch = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = i * 8 + rl;
+        const u32x4 val = *reinterpret_cast<const u32x4*>(ot + row * RB + ((ch ^ (row & 7)) << 4));
+        const int qr = q0 + row;
+        if (qr < p.Sq)
+            *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.osb + (int64_t)qr * p.oss + (int64_t)hd * p.osh + 8 * ch) = val;
+    }
+}
+
 // Adds the parts of the split tail workgroups: O = sum_p O_p / sum_p l_p (same exponent origin in every part) -> bf16.
 // One block = 16 query rows x 16 threads (4 columns each, D = 64).
 __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnParams p) {
@@ -1154,7 +1584,14 @@ int launch_one(AttnParams p, hipStream_t st) {
     }
     bool body16 = false;
     if constexpr (BOUND && !F32 && D == 64 && NW == 8) {
-        if (p.body16 && p.proven) {                          // 16x16x32 body: same grid, same LDS size, same workspace layout
+        if (p.body16 == 2 && p.proven) {                     // 4 waves x 64 rows: same grid, same LDS size, same workspace layout
+            static TcxPerDeviceOnce lds_attr4;
+            constexpr int lds4 = 2 * 6 * 64 * 64 * 2;        // K ring + V ring, 6 slots each
+            const int rc4 = tcx_ensure_dynamic_lds(lds_attr4, reinterpret_cast<const void*>(&attn_fwd4_kernel), lds4, "tcx_attn_fwd");
+            if (rc4 != TCX_OK) return rc4;
+            hipLaunchKernelGGL(attn_fwd4_kernel, dim3(grid), dim3(256), lds4, st, p);
+            body16 = true;
+        } else if (p.body16 && p.proven) {                   // 16x16x32 body: same grid, same LDS size, same workspace layout
             static TcxPerDeviceOnce lds_attr16;
             const int rc16 = tcx_ensure_dynamic_lds(lds_attr16, reinterpret_cast<const void*>(&attn_fwd16_kernel), lds, "tcx_attn_fwd");
             if (rc16 != TCX_OK) return rc16;
@@ -1206,7 +1643,7 @@ extern "C" int tcx_attn_fwd_ws(const void* q, const void* k, const void* v, void
                                void* workspace, int64_t workspace_bytes, void* stream) {
     TCX_CHECK(workspace == nullptr || (tcx_aligned16(workspace) && workspace_bytes >= 0), TCX_E_ALIGN, "tcx_attn_fwd: workspace must be 16-byte aligned");
     TCX_CHECK(q && k && v && o, TCX_E_NULL, "tcx_attn_fwd: null pointer");
-    TCX_CHECK((flags & ~(TCX_ATTN_LOG2_SCORES | TCX_ATTN_BOUND_PROVEN | TCX_ATTN_BODY_16X16X32)) == 0, TCX_E_SHAPE, "tcx_attn_fwd: unknown flags 0x%x", flags);
+    TCX_CHECK((flags & ~(TCX_ATTN_LOG2_SCORES | TCX_ATTN_BOUND_PROVEN | TCX_ATTN_BODY_16X16X32 | TCX_ATTN_BODY_4WAVE)) == 0, TCX_E_SHAPE, "tcx_attn_fwd: unknown flags 0x%x", flags);
     const bool log2s = (flags & TCX_ATTN_LOG2_SCORES) != 0;
     TCX_CHECK(!(flags & TCX_ATTN_BOUND_PROVEN) || (log2s && k_sqmax), TCX_E_SHAPE,
               "tcx_attn_fwd: TCX_ATTN_BOUND_PROVEN needs TCX_ATTN_LOG2_SCORES and k_sqmax");
@@ -1234,7 +1671,7 @@ extern "C" int tcx_attn_fwd_ws(const void* q, const void* k, const void* v, void
     p.nqb = 0; p.nwg = 0;       // set per launch geometry
     p.ws = (float*)workspace; p.ws_bytes = workspace ? (size_t)workspace_bytes : 0; p.n_full = 0; p.split = 1;
     p.proven = (flags & TCX_ATTN_BOUND_PROVEN) ? 1u : 0u;
-    p.body16 = (flags & TCX_ATTN_BODY_16X16X32) ? 1u : 0u;
+    p.body16 = (flags & TCX_ATTN_BODY_4WAVE) ? 2u : (flags & TCX_ATTN_BODY_16X16X32) ? 1u : 0u;
     hipStream_t s = (hipStream_t)stream;
     if (D == 64 && log2s) return out_dtype == TCX_F32 ? launch<64, true, true>(p, s) : launch<64, false, true>(p, s);
     if (D == 64) return out_dtype == TCX_F32 ? launch<64, true, false>(p, s) : launch<64, false, false>(p, s);

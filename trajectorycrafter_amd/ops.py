@@ -98,7 +98,8 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
     if body16 is None:
         body16 = ATTN_BODY16_DEFAULT
     flags = ((_lib.TCX_ATTN_LOG2_SCORES if log2_scores else 0) | (_lib.TCX_ATTN_BOUND_PROVEN if bound_proven else 0) |
-             (_lib.TCX_ATTN_BODY_16X16X32 if (body16 and bound_proven and D == 64 and out_dtype == BF16) else 0))
+             ((_lib.TCX_ATTN_BODY_4WAVE if body16 == 4 else _lib.TCX_ATTN_BODY_16X16X32)
+              if (body16 and bound_proven and D == 64 and out_dtype == BF16) else 0))        # body16: False | True (16x16x32) | 4 (4-wave)
     odt = TCX_F32 if out_dtype == torch.float32 else TCX_BF16
     # scratch of the tail split (balances the last, partly filled round of workgroups; include/tcx_hip.h): caller-owned
     ws_bytes = int(lib.tcx_attn_fwd_workspace_bytes(B, H, Sq, Sk, D, flags, int(k_sqmax is not None), odt)) if split_tail else 0
