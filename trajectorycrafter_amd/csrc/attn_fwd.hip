@@ -1093,6 +1093,8 @@ __global__ __launch_bounds__(512) void attn_fwd16_kernel(const AttnParams p) {
 // (1280 matrix-pipe cycles) beside 64 v_exp_f32 + 32 v_cvt_pk + 24 LDS reads (~1200 issue cycles) instead of 2 x 840.
 // Register plan (hipcc picks ONE register form per MFMA builtin per function, so the MFMAs are inline asm with explicit classes):
 // S tiles of both blocks (exp inputs) in arch VGPRs, O / row-sum accumulators and the Q fragments in AGPRs, never copied in the loop.
+// The kernel must stay SPILL-FREE (checked: 225 + 228 registers, scratch 0): a compiler spill store or copy of an S tile placed right
+// behind an asm MFMA would read registers the MFMA has not written yet — hipcc pads no hazards around asm statements.
 // Hazards the asm statements hide from hipcc (cdna_hip_programming.md 5.7) are kept away by construction: P is converted one slot
 // (5 MFMAs) before the MFMA that reads it, K / V fragments arrive by counted LDS reads, S tiles are exponentiated >= 5 MFMAs after
 // the last MFMA that wrote them, the epilogue waits out the last MFMA explicitly.
@@ -1116,7 +1118,7 @@ __device__ __forceinline__ void l_acc(f32x16& acc, const bf16x8& ones_a, const b
 
 __global__ __launch_bounds__(256) void attn_fwd4_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int D = 64, TILEB = 64 * D * 2, TPB = 2, R = 6, NLD = 2;     // R = 6: see the ring note at super_step
+    constexpr int D = 64, TILEB = 64 * D * 2, TPB = 2, R = 4, NLD = 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
@@ -1308,149 +1310,120 @@ __global__ __launch_bounds__(256) void attn_fwd4_kernel(const AttnParams p) {
         pprev = __builtin_bit_cast(bf16x8, pw);
     };
     // A tile: slots (0,A) (0,B) (1,A) ... (3,B).  V fragments of step ST (shared by both blocks) are read at the start of slot (ST, A)
-    // and used by slots (ST, B) and (ST + 1, A); K fragments of k-step ST + 1 are read at the start of slot (ST, B).  The fragments of
-    // slot (0, A) — K k-step 0 of the tile's K slot into kfa, V step 0 into vfa — are requested by whoever runs BEFORE the tile (the
-    // previous tile's end, ahead of the barrier: `prefetch`), so that a tile never opens with an LDS round trip.  `mid` is called
-    // after slots (0,B) (1,B) (2,B) (3,A) of the tile: the hook where the second tile of a super-step writes the staged tiles to LDS.
-    auto prefetch = [&](const char* kb, const char* vb, bool with_k) __attribute__((always_inline)) {
-        if (with_k) read_k(kb, 0, kfa);
-        read_v(vb, 0, vfa);
-    };
-    auto tile = [&](auto has_next, const char* kb, const char* vb, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], auto&& mid) __attribute__((always_inline)) {
+    // and used by slots (ST, B) and (ST + 1, A); K fragments of k-step ST + 1 are read at the start of slot (ST, B).
+    auto tile = [&](auto has_next, const char* kb, const char* vb, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2]) __attribute__((always_inline)) {
         constexpr bool NEXT = decltype(has_next)::value;
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        if constexpr (NEXT) read_k(kb, 0, kfa);
+        read_v(vb, 0, vfa);
         slot(has_next, I0{}, I0{}, cur, nxt, kfa, vfb);          // (0,A): P of the previous tile's (3,B), V of its step 3 (vfb)
         if constexpr (NEXT) read_k(kb, 1, kfb);
         slot(has_next, I0{}, I1{}, cur, nxt, kfa, vfa);          // (0,B): P of (0,A), V of step 0
-        mid(I0{});
         read_v(vb, 1, vfb);
         slot(has_next, I1{}, I0{}, cur, nxt, kfb, vfa);          // (1,A): P of (0,B), V of step 0
         if constexpr (NEXT) read_k(kb, 2, kfa);
         slot(has_next, I1{}, I1{}, cur, nxt, kfb, vfb);          // (1,B): P of (1,A), V of step 1
-        mid(I1{});
         read_v(vb, 2, vfa);
         slot(has_next, I2{}, I0{}, cur, nxt, kfa, vfb);          // (2,A)
         if constexpr (NEXT) read_k(kb, 3, kfb);
         slot(has_next, I2{}, I1{}, cur, nxt, kfa, vfa);          // (2,B)
-        mid(I2{});
         read_v(vb, 3, vfb);
         slot(has_next, I3{}, I0{}, cur, nxt, kfb, vfa);          // (3,A)
-        mid(I3{});
         slot(has_next, I3{}, I1{}, cur, nxt, kfb, vfb);          // (3,B)
     };
-    auto no_mid = [](auto) {};
 
     constexpr std::integral_constant<int, 0> J0{};
     constexpr std::integral_constant<int, 1> J1{};
-    // Ring of R = 6 slots per operand, tile t in slot t % 6; a super-step = tiles t0, t0 + 1 (PH = t0 % 6), ONE barrier.  With one wave
-    // per SIMD nothing overlaps a barrier, so nothing may WAIT at it (ablation, tools/exp/attn4_ablate.sh: with R = 4 — tiles staged
-    // in super-step s are read in s + 1 — the ds_write burst, its lgkmcnt(0), the barrier and the cold fragment pipeline behind it cost
-    // 471 of 1836 cycles per tile).  Here the tiles loaded at the top of super-step s (K[t0+5], K[t0+6], V[t0+4], V[t0+5]) are written
-    // during its SECOND tile, between slots, into slots last read in s - 1, and first read in s + 2: the barrier ending s only has
-    // to order them before s + 2 (the barrier ending s + 1 would do), the next tile's first fragments are requested before it, and the
-    // waves arrive with nothing pending.
+    auto one_tile = [&](auto masked, auto slot_k, auto slot_v, int t, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2]) __attribute__((always_inline)) {
+        tile(std::true_type{}, kbuf0 + decltype(slot_k)::value * TILEB, vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
+        if constexpr (decltype(masked)::value) {
+            if (t + 1 == ntiles - 1 && (Sk & 63)) mask_tail(nxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // ring / barrier structure of attn_fwd_kernel: tile t in slot t % R, a super-step = 2 tiles, one barrier.  (A 6-slot ring with the
+    // LDS writes between slots of the second tile and the next tile's first fragments requested ahead of the barrier was measured at
+    // the same cycle count, 1853 vs 1836 per tile, and spilled in its remainder code — spills next to asm MFMAs are unsafe, see the
+    // note at the kernel's head — so the simple form stays.)
     auto super_step = [&](auto masked, auto ph, int t0) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph)::value;
 #if !defined(TCX_A4_NOSTAGE) && !defined(TCX_A4_NOLOADS)
-        load_k(J0, t0 + 5);
-        load_v(J0, t0 + 4);
-        load_k(J1, t0 + 6);
-        load_v(J1, t0 + 5);
+        load_k(J0, t0 + TPB + 1);
+        load_v(J0, t0 + TPB);
+        load_k(J1, t0 + TPB + 2);
+        load_v(J1, t0 + TPB + 1);
 #endif
-        tile(std::true_type{}, kbuf0 + ((PH + 1) % R) * TILEB, vbuf0 + (PH % R) * TILEB, sa, sb, no_mid);
-        if constexpr (decltype(masked)::value) {
-            if (t0 + 1 == ntiles - 1 && (Sk & 63)) mask_tail(sb);
-        }
-        prefetch(kbuf0 + ((PH + 2) % R) * TILEB, vbuf0 + ((PH + 1) % R) * TILEB, true);
-        __builtin_amdgcn_sched_barrier(0);
-        tile(std::true_type{}, kbuf0 + ((PH + 2) % R) * TILEB, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa, [&](auto which) __attribute__((always_inline)) {
+        one_tile(masked, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
+        one_tile(masked, std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa);
 #if !defined(TCX_A4_NOSTAGE) && !defined(TCX_A4_NOWRITES)
-            constexpr int W = decltype(which)::value;
-            if constexpr (W == 0) write_k(J0, (PH + 5) % R);
-            if constexpr (W == 1) write_v(J0, (PH + 4) % R);
-            if constexpr (W == 2) write_k(J1, (PH + 6) % R);
-            if constexpr (W == 3) write_v(J1, (PH + 5) % R);
+        write_k(J0, (PH + TPB + 1) % R);
+        write_v(J0, (PH + TPB) % R);
+        write_k(J1, (PH + TPB + 2) % R);
+        write_v(J1, (PH + TPB + 1) % R);
 #endif
-        });
-        if constexpr (decltype(masked)::value) {
-            if (t0 + 2 == ntiles - 1 && (Sk & 63)) mask_tail(sa);
-        }
-        prefetch(kbuf0 + ((PH + 3) % R) * TILEB, vbuf0 + ((PH + 2) % R) * TILEB, true);     // tile t0 + 2: resident since the previous barrier
-        __builtin_amdgcn_sched_barrier(0);
 #if !defined(TCX_A4_NOSTAGE) && !defined(TCX_A4_NOBAR)
         __syncthreads();
 #endif
     };
-    // the last 1 or 2 tiles (everything they read is resident; nothing is staged)
     auto tail = [&](auto ph, int t0) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph)::value;
-        if ((ntiles - 1) - t0 == 1) {
-            tile(std::true_type{}, kbuf0 + ((PH + 1) % R) * TILEB, vbuf0 + (PH % R) * TILEB, sa, sb, no_mid);
-            if (Sk & 63) mask_tail(sb);
-            prefetch(nullptr, vbuf0 + ((PH + 1) % R) * TILEB, false);
-            tile(std::false_type{}, nullptr, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa, no_mid);
+        const int rem = (ntiles - 1) - t0;
+        if (rem == 1) {
+            one_tile(std::true_type{}, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
+            tile(std::false_type{}, kbuf0, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
         } else {
-            tile(std::false_type{}, nullptr, vbuf0 + (PH % R) * TILEB, sa, sb, no_mid);
+            tile(std::false_type{}, kbuf0, vbuf0 + (PH % R) * TILEB, sa, sb);
         }
     };
 
-    // prologue: K[0 .. 4], V[0 .. 3] into their slots, S(0) of both blocks, the first tile's fragments
-    load_k(J0, 0); load_v(J0, 0); load_k(J1, 1); load_v(J1, 1);
-    write_k(J0, 0); write_v(J0, 0); write_k(J1, 1); write_v(J1, 1);
-    load_k(J0, 2); load_v(J0, 2); load_k(J1, 3); load_v(J1, 3);
-    write_k(J0, 2); write_v(J0, 2); write_k(J1, 3); write_v(J1, 3);
-    load_k(J0, 4);
-    write_k(J0, 4);
+    // prologue: K[0 .. 2], V[0 .. 1] into their slots, S(0) of both blocks
+    load_k(J0, 0);
+    load_v(J0, 0);
+    load_k(J1, 1);
+    load_v(J1, 1);
+    write_k(J0, 0);
+    write_v(J0, 0);
+    write_k(J1, 1);
+    write_v(J1, 1);
+    load_k(J0, TPB);
+    write_k(J0, TPB % R);
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        read_k(kbuf0, ks, kfb);
+        read_k(kbuf0, ks, kfa);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                if (ks == 0) mf::s_first(sa[blk][t], kfb[t], qf[blk][ks]);
-                else mf::s_acc(sa[blk][t], kfb[t], qf[blk][ks]);
+                if (ks == 0) mf::s_first(sa[blk][t], kfa[t], qf[blk][ks]);
+                else mf::s_acc(sa[blk][t], kfa[t], qf[blk][ks]);
             }
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last QK^T MFMA has written S before anything reads it
     if (ntiles == 1 && (Sk & 63)) mask_tail(sa);
-    prefetch(kbuf0 + 1 * TILEB, vbuf0, ntiles > 1);
-    __syncthreads();                                        // K slot 0 is written again during the first super-step
+    __syncthreads();
 
 #ifdef TCX_ATTN_STAMP
     const unsigned long long tC0 = __builtin_amdgcn_s_memtime(), tR0 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
     {
-        using P0 = std::integral_constant<int, 0>; using P2 = std::integral_constant<int, 2>; using P4 = std::integral_constant<int, 4>;
-        const std::false_type plain{};
-        const std::true_type masked{};
         int t0 = 0;
-        // steady state, three super-steps (one turn of the ring) per iteration: a super-step computes the scores up to tile t0 + 2; while
-        // that is not the last tile there is no mask code
-        for (; t0 + 6 < ntiles - 1; t0 += 6) {
-            super_step(plain, P0{}, t0);
-            super_step(plain, P2{}, t0 + 2);
-            super_step(plain, P4{}, t0 + 4);
+        for (; t0 + 2 * TPB < ntiles - 1; t0 += 2 * TPB) {   // steady state: never reaches the last key tile -> no mask code
+            super_step(std::false_type{}, std::integral_constant<int, 0>{}, t0);
+            super_step(std::false_type{}, std::integral_constant<int, TPB>{}, t0 + TPB);
         }
-        // remainder: 0..2 plain super-steps, at most one that reaches the last tile exactly (masked), then the last 1 or 2 tiles
-        if (t0 + 2 < ntiles - 1) {
-            super_step(plain, P0{}, t0);
-            t0 += 2;
-            if (t0 + 2 < ntiles - 1) {
-                super_step(plain, P2{}, t0);
-                t0 += 2;
-                if (t0 + 2 <= ntiles - 1) { super_step(masked, P4{}, t0); tail(P0{}, t0 + 2); }
-                else tail(P4{}, t0);
-            } else {
-                if (t0 + 2 <= ntiles - 1) { super_step(masked, P2{}, t0); tail(P4{}, t0 + 2); }
-                else tail(P2{}, t0);
-            }
+        if (t0 + 2 * TPB <= ntiles - 1) {
+            super_step(std::true_type{}, std::integral_constant<int, 0>{}, t0);
+            super_step(std::true_type{}, std::integral_constant<int, TPB>{}, t0 + TPB);
+            t0 += 2 * TPB;
+        }
+        if (t0 + TPB <= ntiles - 1) {
+            super_step(std::true_type{}, std::integral_constant<int, 0>{}, t0);
+            tail(std::integral_constant<int, TPB>{}, t0 + TPB);
         } else {
-            if (t0 + 2 <= ntiles - 1) { super_step(masked, P0{}, t0); tail(P2{}, t0 + 2); }
-            else tail(P0{}, t0);
+            tail(std::integral_constant<int, 0>{}, t0);
         }
     }
 #ifdef TCX_ATTN_STAMP
@@ -1586,10 +1559,9 @@ int launch_one(AttnParams p, hipStream_t st) {
     if constexpr (BOUND && !F32 && D == 64 && NW == 8) {
         if (p.body16 == 2 && p.proven) {                     // 4 waves x 64 rows: same grid, same LDS size, same workspace layout
             static TcxPerDeviceOnce lds_attr4;
-            constexpr int lds4 = 2 * 6 * 64 * 64 * 2;        // K ring + V ring, 6 slots each
-            const int rc4 = tcx_ensure_dynamic_lds(lds_attr4, reinterpret_cast<const void*>(&attn_fwd4_kernel), lds4, "tcx_attn_fwd");
+            const int rc4 = tcx_ensure_dynamic_lds(lds_attr4, reinterpret_cast<const void*>(&attn_fwd4_kernel), lds, "tcx_attn_fwd");
             if (rc4 != TCX_OK) return rc4;
-            hipLaunchKernelGGL(attn_fwd4_kernel, dim3(grid), dim3(256), lds4, st, p);
+            hipLaunchKernelGGL(attn_fwd4_kernel, dim3(grid), dim3(256), lds, st, p);
             body16 = true;
         } else if (p.body16 && p.proven) {                   // 16x16x32 body: same grid, same LDS size, same workspace layout
             static TcxPerDeviceOnce lds_attr16;
