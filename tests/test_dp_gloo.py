@@ -55,6 +55,25 @@ def test_two_ranks_shard_and_gather():
         assert torch.equal(out, expect)                              # every rank holds all results, in trajectory order
 
 
+def test_two_ranks_ragged_count():
+    """3 trajectories on 2 ranks: rank 1 pads its block for the single all-gather, the padding is dropped, order is by trajectory."""
+    world, n_items = 2, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = torch.cat([torch.randn(1, 3, 4, generator=torch.Generator().manual_seed(100 + i)) + i for i in range(n_items)])
+    for rank, calls, out in res:
+        assert calls == list(range(rank, n_items, world))
+        assert out.shape == (n_items, 3, 4) and torch.equal(out, expect)
+
+
 def test_single_process_is_passthrough():
     sys.path.insert(0, ROOT)
     from trajectorycrafter_amd import dp

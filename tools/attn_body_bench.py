@@ -5,13 +5,21 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from trajectorycrafter_amd import ops
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+_fused = "--fused" in sys.argv
+_args = [a for a in sys.argv[1:] if a != "--fused"]
+iters = int(_args[0]) if len(_args) > 0 else 20
+rounds = int(_args[1]) if len(_args) > 1 else 6
 B, S, H, D = 2, 17776, 48, 64
 g = torch.Generator(device="cuda").manual_seed(0)
-q = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16, generator=g) * (D ** -0.5 * 1.4426950408889634)
-k = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16, generator=g)
-v = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16, generator=g)
+if _fused:                           # the model's layout: q, k, v are column slices of ONE [B, S, 3 H D] projection output (row stride 18 KB)
+    qkv = torch.randn(B, S, 3 * H * D, device="cuda", dtype=torch.bfloat16, generator=g)
+    q, k, v = (t.view(B, S, H, D) for t in qkv.chunk(3, -1))
+    q.mul_(D ** -0.5 * 1.4426950408889634)
+    print("layout: fused QKV views (row stride", q.stride(1) * 2, "bytes)")
+else:
+    q = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16, generator=g) * (D ** -0.5 * 1.4426950408889634)
+    k = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16, generator=g)
+    v = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16, generator=g)
 ksq = (k.float() ** 2).sum(-1).amax(1).contiguous()
 flop = 4.0 * S * S * D * H * B
 def t(body16):

@@ -56,16 +56,19 @@ def all_gather_cat(local: torch.Tensor) -> torch.Tensor:
 def run_trajectories(run_one: Callable[[int], torch.Tensor], n_items: int, gather: bool = True) -> torch.Tensor:
     """Run `run_one(i)` (-> tensor [1, ...]) for the trajectories this rank owns and all-gather.
 
-    With n_items a multiple of the world size the result on every rank is `[n_items, ...]` ordered by
-    trajectory index (rank-major gather re-ordered to trajectory order)."""
+    The result on every rank is `[n_items, ...]` ordered by trajectory index (rank-major gather re-ordered to trajectory order).
+    n_items need not be a multiple of the world size: ranks with one trajectory fewer pad their block with zeros for the single
+    all-gather and the padding is dropped afterwards (every rank must own at least one trajectory: n_items >= world size)."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
-    if n_items % world != 0:
-        raise ValueError(f"n_items ({n_items}) must be a multiple of the world size ({world}) for a single all-gather")
+    if n_items < world:
+        raise ValueError(f"n_items ({n_items}) must be at least the world size ({world}): every rank runs at least one trajectory")
     mine = shard_indices(n_items, rank, world)
     local = torch.cat([run_one(i) for i in mine], dim=0)
     if not gather or world == 1:
         return local
-    allr = all_gather_cat(local)                       # [world * per, ...] rank-major
-    per = len(mine)
-    order = [r * per + j for j in range(per) for r in range(world)]    # trajectory index i = j*world + r
+    per = (n_items + world - 1) // world
+    if len(mine) < per:                                 # ragged: pad to the common block size
+        local = torch.cat([local, local.new_zeros((per - len(mine),) + tuple(local.shape[1:]))], dim=0)
+    allr = all_gather_cat(local)                        # [world * per, ...] rank-major
+    order = [(i % world) * per + i // world for i in range(n_items)]    # trajectory i = j * world + r sits at row r * per + j
     return allr[torch.tensor(order, device=allr.device)]
