@@ -462,6 +462,16 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 #else
     constexpr bool FSUM = false;
 #endif
+    // Third form (-DTCX_ATTN_FINE_SUM_4X4): v_mfma_f32_4x4x4_16b_bf16 with an all-ones A operand adds the FOUR bf16 values a lane
+    // holds in two packed P registers into that lane's accumulator (every block row of ones . B is the column sum, and a lane's
+    // column is its own k-values): 2 short MFMAs per 16-key step (8 per tile) instead of 32 v_add.
+#ifdef TCX_ATTN_FINE_SUM_4X4
+    constexpr bool F4 = FINE && !FSUM;
+#else
+    constexpr bool F4 = false;
+#endif
+    f32x4 lacc4 = {0.f, 0.f, 0.f, 0.f}, lacc4b = {0.f, 0.f, 0.f, 0.f};
+    const s16x4 ones4 = {0x3f80, 0x3f80, 0x3f80, 0x3f80};
     bf16x8 pprev, vprev[DT];
 #pragma unroll
     for (int j = 0; j < 8; ++j) pprev[j] = (__bf16)0.0f;
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             auto soft2 = [&](int j0) __attribute__((always_inline)) {
                 const float e0 = __builtin_amdgcn_exp2f(cur[t][8 * s2 + j0]);
                 const float e1 = __builtin_amdgcn_exp2f(cur[t][8 * s2 + j0 + 1]);
-                if constexpr (!FSUM) {
+                if constexpr (!FSUM && !F4) {
                     ls[j0 & 3] += e0;
                     ls[(j0 + 1) & 3] += e1;
                 }
@@ -514,11 +524,21 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
                 else if (kb_after) read_k_from(kb_after, 0, kfn);      // step 3: kfn is kfa, what the next tile's step 0 uses
             }
             o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vprev[0], pprev, o[0], 0, 0, 0);
+            if constexpr (F4) {                          // the previous step's P (converted a step ago: no VALU -> MFMA wait states)
+                const u32x4 pv = __builtin_bit_cast(u32x4, pprev);
+                const u32x2 lo = {pv[0], pv[1]};
+                lacc4 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, lo), lacc4, 0, 0, 0);
+            }
             soft2(0);
             __builtin_amdgcn_sched_barrier(0);
             read_v(st, 0, vcur[0]);
             o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vprev[1], pprev, o[1], 0, 0, 0);
             if constexpr (FSUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pprev, lacc, 0, 0, 0);
+            if constexpr (F4) {
+                const u32x4 pv = __builtin_bit_cast(u32x4, pprev);
+                const u32x2 hi = {pv[2], pv[3]};
+                lacc4b = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, hi), lacc4b, 0, 0, 0);
+            }
             soft2(2);
             __builtin_amdgcn_sched_barrier(0);
             read_v(st, 1, vcur[1]);
@@ -527,9 +547,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (NEXT) nxt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[st], chain_c(st == 0, nxt[1]), 0, 0, 0);
             soft2(6);
-            if constexpr (!FSUM) asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]));
+            if constexpr (!FSUM && !F4) asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]));
             __builtin_amdgcn_sched_barrier(0);
             pf = __builtin_bit_cast(bf16x8, pw);
+
             pprev = pf;
             vprev[0] = vcur[0];
             vprev[1] = vcur[1];
@@ -672,8 +693,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vprev[dt], pprev, o[dt], 0, 0, 0);
         if constexpr (FSUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pprev, lacc, 0, 0, 0);
+        if constexpr (F4) {
+            const u32x4 pv = __builtin_bit_cast(u32x4, pprev);
+            const u32x2 lo = {pv[0], pv[1]}, hi = {pv[2], pv[3]};
+            lacc4 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, lo), lacc4, 0, 0, 0);
+            lacc4b = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, hi), lacc4b, 0, 0, 0);
+        }
     }
-    if constexpr (!(FAST && kSumMfma) && !FSUM) l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+    if constexpr (F4) l += lacc4[0] + lacc4b[0];
+    else if constexpr (!(FAST && kSumMfma) && !FSUM) l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
 
     // ---- epilogue: combine the two half-wave partial sums, normalise, store O[q][d] ----
     if constexpr ((FAST && kSumMfma) || FSUM) {
