@@ -232,6 +232,15 @@ int tcx_conv3d_route(int32_t T_in, int32_t H_in, int32_t W_in, int32_t Cin, int3
  * Replaces: the avg_pool1d branch the encoder's down blocks run (built models/autoencoder_magvit.py:423-435). */
 int tcx_avgpool_t(const void* x, void* y, int32_t N, int32_t T, int64_t S, int32_t C, void* stream);
 
+/* ---- seam blend of the tiled VAE decode ---------------------------------------------------------
+ * b[o, y, i] = a[o, y, i] * (1 - y/ext) + b[o, y, i] * (y/ext) for o < outer, y < ext, i < inner, IN PLACE on b (bf16); `a` points at
+ * the first of the LAST `ext` rows (blend_v) or columns (blend_h) of the neighbouring tile.  Element strides; rounding as the
+ * reference's eager bf16 arithmetic: each product to bf16, then the sum (weights are python floats, i.e. fp32 scalars in the op).
+ * Channels-last tiles [N, T, H, W, C]: blend_v = (outer N*T, ext along H, inner W*C), blend_h = (outer N*T*H, ext along W, inner C).
+ * Replaces: AutoencoderKLCogVideoX.blend_v / blend_h (models/autoencoder_magvit.py:1282-1301) as tiled_decode calls them (:1376-1379). */
+int tcx_blend_ramp_bf16(const void* a, void* b, int64_t outer, int32_t ext, int64_t inner, int64_t a_outer_stride, int64_t a_ext_stride,
+                        int64_t b_outer_stride, int64_t b_ext_stride, void* stream);
+
 /* ---- K13: GroupNorm statistics + fused GroupNorm * SpatialNorm modulate + SiLU ----------------
  * stats: per (n, group) mean / rstd over (T, H, W, C/G) of channels-last x [N, spatial, C] bf16.
  *   Two launches: per-channel shifted partial sums of `nsplit` row slabs into

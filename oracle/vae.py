@@ -2,7 +2,7 @@
 
 Follows reference models/autoencoder_magvit.py: CogVideoXCausalConv3d :76-163,
 CogVideoXSpatialNorm3D :166-212, CogVideoXResnetBlock3D :215-355, blocks :358-660,
-encoder :663-800, decoder :803-953, encode/_decode :1176-1253.  The conv cache is an
+encoder :663-800, decoder :803-953, encode/_decode :1176-1253, tiled_decode / blend_v / blend_h :1282-1392.  The conv cache is an
 explicit dict (the reference hides it in module state, :134,157).
 """
 from __future__ import annotations
@@ -145,6 +145,75 @@ def vae_decode(sd: dict, config: dict, z: torch.Tensor, prec: str = "fp32",
             break
         dec.append(decoder_forward(p, sd, cfg, z[:, :, s:e], cache))
     return p.out(torch.cat(dec, dim=2))
+
+
+def tiling_params(config: dict, tile_sample_min_height=None, tile_sample_min_width=None,
+                  tile_overlap_factor_height=None, tile_overlap_factor_width=None) -> dict:
+    """The numbers `__init__` (:1081-1098) and `enable_tiling` (:1109-1153) derive (`x or default`, as the reference)."""
+    cfg = dict(DEFAULT_CONFIG)
+    cfg.update(config)
+    down = 2 ** (len(cfg["block_out_channels"]) - 1)
+    th = tile_sample_min_height or cfg["sample_height"] // 2
+    tw = tile_sample_min_width or cfg["sample_width"] // 2
+    return dict(tile_sample_min_height=th, tile_sample_min_width=tw,
+                tile_latent_min_height=int(th / down), tile_latent_min_width=int(tw / down),
+                tile_overlap_factor_height=tile_overlap_factor_height or 1 / 6,
+                tile_overlap_factor_width=tile_overlap_factor_width or 1 / 5)
+
+
+def _blend(p: Prec, a: torch.Tensor, b: torch.Tensor, blend_extent: int, dim: int) -> torch.Tensor:
+    """blend_v (dim 3, :1282-1291) / blend_h (dim 4, :1293-1301): IN PLACE on b; in bf16 the reference's eager arithmetic rounds
+    each product and the sum (python-float weights enter at fp32)."""
+    blend_extent = min(a.shape[dim], b.shape[dim], blend_extent)
+    for y in range(blend_extent):
+        wa = float(np.float32(1 - y / blend_extent))
+        wb = float(np.float32(y / blend_extent))
+        ia = [slice(None)] * 5
+        ib = [slice(None)] * 5
+        ia[dim] = a.shape[dim] - blend_extent + y
+        ib[dim] = y
+        b[tuple(ib)] = p.R(p.R(a[tuple(ia)] * wa) + p.R(b[tuple(ib)] * wb))
+    return b
+
+
+def vae_tiled_decode(sd: dict, config: dict, z: torch.Tensor, prec: str = "fp32", **tiling) -> torch.Tensor:
+    """reference `tiled_decode` :1303-1392 (entered from `_decode` :1222-1225 when the latent exceeds the tile): every spatial tile
+    is decoded with its own conv cache over the temporal chunks, blended with the ALREADY BLENDED tile above and to its left
+    (the blends write in place, :1376-1379), cropped to the row limits and concatenated."""
+    cfg = dict(DEFAULT_CONFIG)
+    cfg.update(config)
+    tp = tiling_params(config, **tiling)
+    p = Prec(prec)
+    z = p.R(z)
+    T, height, width = z.shape[2:]
+    lh, lw = tp["tile_latent_min_height"], tp["tile_latent_min_width"]
+    if not (width > lw or height > lh):
+        return vae_decode(sd, config, z, prec)
+    overlap_h = int(lh * (1 - tp["tile_overlap_factor_height"]))
+    overlap_w = int(lw * (1 - tp["tile_overlap_factor_width"]))
+    blend_h_ext = int(tp["tile_sample_min_height"] * tp["tile_overlap_factor_height"])
+    blend_w_ext = int(tp["tile_sample_min_width"] * tp["tile_overlap_factor_width"])
+    limit_h = tp["tile_sample_min_height"] - blend_h_ext
+    limit_w = tp["tile_sample_min_width"] - blend_w_ext
+    rows = []
+    for i in range(0, height, overlap_h):
+        row = []
+        for j in range(0, width, overlap_w):
+            cache: dict = {}
+            time = [decoder_forward(p, sd, cfg, z[:, :, s:e, i:i + lh, j:j + lw], cache) for s, e in _chunks(T, 2)]
+            row.append(torch.cat(time, dim=2))           # T == 1: an empty list, the reference raises here too (:1345-1364)
+        rows.append(row)
+    result_rows = []
+    for i, row in enumerate(rows):
+        result_row = []
+        for j, tile in enumerate(row):
+            if i > 0:
+                tile = _blend(p, rows[i - 1][j], tile, blend_h_ext, 3)
+            if j > 0:
+                tile = _blend(p, row[j - 1], tile, blend_w_ext, 4)
+            result_row.append(tile[:, :, :, :limit_h, :limit_w])
+        result_rows.append(torch.cat(result_row, dim=4))
+    return p.out(torch.cat(result_rows, dim=3))
 
 
 def vae_encode(sd: dict, config: dict, x: torch.Tensor, prec: str = "fp32") -> dr.DiagonalGaussian:

@@ -492,8 +492,39 @@ def make_poses():
               frames=49))
 
 
+TILED_VAE = dict(TINY_VAE, sample_height=96, sample_width=80)   # tiles 48 x 40 px = 6 x 5 latent rows / columns, strides 5 / 4, blends 8 / 8
+
+
+def make_tiled():
+    """vae_tiled_tiny.safetensors: the reference's `enable_tiling()` + `decode` (autoencoder_magvit.py:1109-1153, 1222-1225,
+    1303-1392) on a 12 x 10 latent: 3 x 3 tiles with ragged last row / column, 2 temporal chunks per tile.  Weights are those of
+    vae_tiny.safetensors (same seed, same shapes)."""
+    if not os.path.isdir(REF):
+        raise SystemExit("make_golden.py needs /root/reference (build container only)")
+    install_scaffolding()
+    sys.path.insert(0, REF)
+    from models.autoencoder_magvit import AutoencoderKLCogVideoX
+    vae_sd = bf16_round(iw.random_state_dict(iw.vae_param_shapes(TINY_VAE), seed=1))
+    vae = AutoencoderKLCogVideoX(**TILED_VAE).eval()
+    print("vae load:", vae.load_state_dict(vae_sd, strict=True))
+    g = torch.Generator().manual_seed(777)
+    z = torch.randn(1, 16, 5, 12, 10, generator=g)
+    with torch.no_grad():
+        vae.enable_tiling()
+        dec = vae.decode(z).sample
+        vae.enable_tiling(tile_sample_min_height=64, tile_sample_min_width=64, tile_overlap_factor_height=0.25,
+                          tile_overlap_factor_width=0.25)          # 8 x 8 latent tiles, stride 6, blend 16, limit 48
+        dec2 = vae.decode(z[:, :, :3]).sample                      # one temporal chunk
+    print("tiled decode:", tuple(dec.shape), tuple(dec2.shape))
+    save("vae_tiled_tiny.safetensors", dict(z=z, decoded_tiled=dec, decoded_tiled_64=dec2),
+         dict(config=repr(TILED_VAE), weights="vae_tiny.safetensors",
+              source="reference AutoencoderKLCogVideoX.enable_tiling() / .decode (tiled_decode, blend_v, blend_h)"))
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["warp"]:
+    if sys.argv[1:] == ["tiled"]:
+        make_tiled()
+    elif sys.argv[1:] == ["warp"]:
         make_warp()
     elif sys.argv[1:] == ["poses"]:
         make_poses()
@@ -501,3 +532,4 @@ if __name__ == "__main__":
         main()
         make_warp()
         make_poses()
+        make_tiled()

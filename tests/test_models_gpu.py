@@ -191,6 +191,76 @@ def test_vae_decode_tiny(golden, gpu):
     assert torch.equal(fr, (dec / 2 + 0.5).clamp(0, 1).float())
 
 
+def test_vae_tiled_decode_tiny(golden, gpu):
+    """enable_tiling() + decode against the reference's own tiled decode (fixture) and the oracle under the bf16 contract:
+    3 x 3 ragged tiles x 2 temporal chunks, seams blended in place by tcx_blend_ramp_bf16."""
+    from trajectorycrafter_amd.models.autoencoder_magvit import AutoencoderKLCogVideoX
+    t, meta = golden("vae_tiled_tiny.safetensors")
+    tv, _ = golden(meta["weights"])
+    cfg = ast.literal_eval(meta["config"])
+    sd = _weights(tv)
+    vae = AutoencoderKLCogVideoX(**cfg)
+    vae.load_state_dict(sd, strict=True)
+    vae = vae.to(gpu, BF).eval()
+    sdf = {k: v.float() for k, v in sd.items()}
+    z = t["z"].to(BF)
+    plain = vae.decode(z.to(gpu)).sample
+    vae.enable_tiling()
+    assert (vae.tile_latent_min_height, vae.tile_latent_min_width) == (6, 5)
+    dec = vae.decode(z.to(gpu)).sample
+    assert dec.shape == (1, 3, 17, 96, 80) and not torch.equal(dec, plain)
+    _check_deep(dec, ovae.vae_tiled_decode(sdf, cfg, z.float(), prec="bf16"), t["decoded_tiled"], "vae tiled decode tiny (9 tiles, 2 chunks)")
+    assert torch.equal(vae.decode(z.to(gpu)).sample, dec)                          # re-entrant
+    assert torch.equal(vae.decode_to_frames(z.to(gpu)), (dec / 2 + 0.5).clamp(0, 1).float())
+    assert torch.equal(vae.decode_cl_bf16(z.to(gpu)).permute(0, 4, 1, 2, 3), dec)
+    # caller-set geometry, one temporal chunk
+    kw = dict(tile_sample_min_height=64, tile_sample_min_width=64, tile_overlap_factor_height=0.25, tile_overlap_factor_width=0.25)
+    vae.enable_tiling(**kw)
+    d2 = vae.decode(z[:, :, :3].to(gpu)).sample
+    _check_deep(d2, ovae.vae_tiled_decode(sdf, cfg, z[:, :, :3].float(), prec="bf16", **kw), t["decoded_tiled_64"], "vae tiled decode, 64 px tiles")
+    # a latent inside one tile takes the plain path (:1222-1225); a single frame fails like the reference's empty concat
+    small = z[:, :, :, :8, :8].contiguous().to(gpu)
+    tiled_small = vae.decode(small).sample
+    vae.disable_tiling()
+    assert torch.equal(tiled_small, vae.decode(small).sample)
+    assert torch.equal(vae.decode(z.to(gpu)).sample, plain)
+    vae.enable_tiling()
+    with pytest.raises(ValueError, match="single frames"):
+        vae.decode(z[:, :, :1].to(gpu))
+    # slicing (:1274-1278) is the batched decode, bit for bit
+    vae.disable_tiling()
+    z2 = torch.cat([z, z.flip(4)], 0).to(gpu)
+    batched = vae.decode(z2).sample
+    vae.enable_slicing()
+    assert torch.equal(vae.decode(z2).sample, batched)
+    vae.disable_slicing()
+
+
+def test_blend_ramp_bit_exact(gpu):
+    """tcx_blend_ramp_bf16 against the reference's eager bf16 loop (blend_v / blend_h, autoencoder_magvit.py:1282-1301) run by
+    torch on the device: same three roundings per element -> identical bits; ragged extents (min with both tile sizes)."""
+    from trajectorycrafter_amd import ops
+    from trajectorycrafter_amd._lib import TcxError
+    g = torch.Generator(device=gpu).manual_seed(3)
+    for (Ha, Wa), (Hb, Wb), ext, dim in (((16, 12), (16, 12), 5, 2), ((16, 12), (7, 12), 9, 2), ((16, 12), (16, 5), 8, 3),
+                                          ((3, 12), (16, 12), 8, 2), ((16, 12), (16, 9), 1, 3), ((40, 72), (40, 72), 40, 3)):
+        a = torch.randn(2, 3, Ha, Wa, 3, device=gpu, generator=g).to(BF)
+        b = torch.randn(2, 3, Hb, Wb, 3, device=gpu, generator=g).to(BF)
+        want = b.clone()
+        e = min(a.shape[dim], b.shape[dim], ext)
+        for y in range(e):                                   # the reference's loop, on [N,T,H,W,C] instead of [N,C,T,H,W]
+            if dim == 2:
+                want[:, :, y] = a[:, :, -e + y] * (1 - y / e) + want[:, :, y] * (y / e)
+            else:
+                want[:, :, :, y] = a[:, :, :, -e + y] * (1 - y / e) + want[:, :, :, y] * (y / e)
+        a0 = a.clone()
+        got = ops.blend_ramp(a, b, ext, dim)
+        assert got is b and torch.equal(b, want) and torch.equal(a, a0), (Ha, Wa, Hb, Wb, ext, dim)
+    with pytest.raises(TcxError):
+        ops.blend_ramp(a, b[:, :, :, :, :2].contiguous(), 4, 2)
+    assert ops.blend_ramp(a, b, 0, 2) is b
+
+
 def test_vae_encode_tiny(golden, gpu):
     """HIP VAE encoder (stride-2 conv gather, temporal avg-pool, GroupNorm+SiLU, 4-frame chunks with conv cache)."""
     from trajectorycrafter_amd.models.autoencoder_magvit import AutoencoderKLCogVideoX

@@ -153,6 +153,30 @@ def test_default_width_decode_small_vs_oracle(vae_default, gpu):
     assert torch.equal(d2[1:], vae.decode(z.flip(3).contiguous()).sample)
 
 
+def test_default_width_tiled_decode_vs_oracle(vae_default, gpu):
+    """enable_tiling() at the default widths: 64 x 96 px tiles (8 x 12 latent) over a 16 x 20 latent -> 3 x 3 ragged tiles, two
+    temporal chunks each, through the MFMA conv kernels; blended seams; against the oracle's restatement of tiled_decode."""
+    vae, cfg, sdf = vae_default
+    g = torch.Generator(device=gpu).manual_seed(15)
+    z = torch.randn(1, 16, 5, 16, 20, device=gpu, generator=g).to(BF)
+    kw = dict(tile_sample_min_height=64, tile_sample_min_width=96, tile_overlap_factor_height=0.25, tile_overlap_factor_width=0.25)
+    try:
+        vae.enable_tiling(**kw)
+        dec = vae.decode(z).sample
+    finally:
+        vae.disable_tiling()
+        vae.enable_tiling()                                  # back to the constructor's geometry ...
+        vae.tile_sample_min_height, vae.tile_sample_min_width = cfg["sample_height"] // 2, cfg["sample_width"] // 2
+        vae.tile_latent_min_height, vae.tile_latent_min_width = vae.tile_sample_min_height // 8, vae.tile_sample_min_width // 8
+        vae.tile_overlap_factor_height, vae.tile_overlap_factor_width = 1 / 6, 1 / 5
+        vae.disable_tiling()                                 # ... and off (module-scoped fixture)
+    assert dec.shape == (1, 3, 17, 128, 160)
+    with torch.no_grad():
+        con = ovae.vae_tiled_decode(sdf, cfg, z.float(), prec="bf16", **kw).float()
+        ex = ovae.vae_tiled_decode(sdf, cfg, z.float(), prec="fp32", **kw).float()
+    _check_deep(dec, con, ex, "default-width tiled decode, 17 frames 128x160 (9 tiles)")
+
+
 def test_default_width_encode_small_vs_oracle(vae_default, gpu):
     """[1,3,17,64,96] -> posterior over [1,16,5,8,12]: chunks of 5, 4, 4, 4 frames (remainder folded into the first, :1199-1205)."""
     vae, cfg, sdf = vae_default

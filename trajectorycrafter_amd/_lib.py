@@ -41,6 +41,7 @@ SIGNATURES = {
     "tcx_conv3d_cl": [_vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 16 + [_vp, _vp],
     "tcx_conv3d_route": [_i32] * 14,
     "tcx_avgpool_t": [_vp, _vp, _i32, _i32, _i64, _i32, _vp],
+    "tcx_blend_ramp_bf16": [_vp, _vp, _i64, _i32, _i64, _i64, _i64, _i64, _i64, _vp],
     "tcx_scale_sqmax_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _f32, _vp, _vp],
     "tcx_gemm_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp],
     "tcx_warp_forward": [_vp] * 10 + [_i32, _i32, _i32, _i32, _vp],

@@ -277,7 +277,35 @@ __global__ __launch_bounds__(256) void avgpool_t_kernel(const uint16_t* x, uint1
     }
 }
 
+// tile-seam blend of the tiled VAE decode: b[o, y, i] = a[o, y, i] * (1 - y/ext) + b[o, y, i] * (y/ext), y < ext, with the
+// reference's eager bf16 roundings (each product, then the sum; the python-float weights enter at fp32)
+__global__ __launch_bounds__(256) void blend_ramp_kernel(const uint16_t* a, uint16_t* b, int64_t outer, int32_t ext, int64_t inner,
+                                                         int64_t a_so, int64_t a_se, int64_t b_so, int64_t b_se) {
+    const int64_t per = (int64_t)ext * inner, total = outer * per;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = idx / per, r = idx - o * per;
+        const int y = (int)(r / inner);
+        const int64_t i = r - (int64_t)y * inner;
+        const float wb = (float)((double)y / (double)ext), wa = (float)(1.0 - (double)y / (double)ext);
+        uint16_t* bp = b + o * b_so + (int64_t)y * b_se + i;
+        const float av = round_bf16(bf16_bits_to_f32(a[o * a_so + (int64_t)y * a_se + i]) * wa);
+        const float bv = round_bf16(bf16_bits_to_f32(*bp) * wb);
+        *bp = (uint16_t)(__float_as_uint(round_bf16(av + bv)) >> 16);
+    }
+}
+
 }  // namespace
+
+extern "C" int tcx_blend_ramp_bf16(const void* a, void* b, int64_t outer, int32_t ext, int64_t inner, int64_t a_outer_stride,
+                                   int64_t a_ext_stride, int64_t b_outer_stride, int64_t b_ext_stride, void* stream) {
+    TCX_CHECK(a && b, TCX_E_NULL, "tcx_blend_ramp_bf16: null pointer");
+    TCX_CHECK(outer > 0 && ext > 0 && inner > 0, TCX_E_SHAPE, "tcx_blend_ramp_bf16: outer, ext and inner must be positive");
+    TCX_CHECK(a_ext_stride >= inner && b_ext_stride >= inner && a_outer_stride >= (int64_t)ext * a_ext_stride &&
+              b_outer_stride >= (int64_t)ext * b_ext_stride, TCX_E_SHAPE, "tcx_blend_ramp_bf16: strides shorter than the blended strip");
+    hipLaunchKernelGGL(blend_ramp_kernel, dim3(grid_for(outer * ext * inner)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a,
+                       (uint16_t*)b, outer, ext, inner, a_outer_stride, a_ext_stride, b_outer_stride, b_ext_stride);
+    TCX_LAUNCH_RET();
+}
 
 extern "C" int tcx_avgpool_t(const void* x, void* y, int32_t N, int32_t T, int64_t S, int32_t C, void* stream) {
     TCX_CHECK(x && y, TCX_E_NULL, "tcx_avgpool_t: null pointer");

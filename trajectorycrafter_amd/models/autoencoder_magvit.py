@@ -431,16 +431,34 @@ class AutoencoderKLCogVideoX(ModelMixin, ConfigMixin):
         self.use_slicing = False
         self.use_tiling = False
         self.num_latent_frames_batch_size = 2          # reference :1079
+        down = 2 ** (len(block_out_channels) - 1)      # tile geometry, reference :1081-1098
+        self.tile_sample_min_height = sample_height // 2
+        self.tile_sample_min_width = sample_width // 2
+        self.tile_latent_min_height = int(self.tile_sample_min_height / down)
+        self.tile_latent_min_width = int(self.tile_sample_min_width / down)
+        self.tile_overlap_factor_height = 1 / 6
+        self.tile_overlap_factor_width = 1 / 5
 
-    # ---- knobs kept for API compatibility (:1109-1174) ----
-    def enable_tiling(self, *a, **k):
-        raise NotImplementedError("tiled decode (:1282-1392) is off by default in the reference and not built: "
-                                  "288 GB of HBM holds the full-frame activations")
+    # ---- tiling / slicing knobs (:1109-1174) ----
+    def enable_tiling(self, tile_sample_min_height: Optional[int] = None, tile_sample_min_width: Optional[int] = None,
+                      tile_overlap_factor_height: Optional[float] = None, tile_overlap_factor_width: Optional[float] = None) -> None:
+        """reference :1109-1153 (`x or current`).  288 GB of HBM never needs it; it changes the RESULT (every tile sees zero
+        padding at its own border and the seams are ramps), so it is built for callers that ran the reference with it on."""
+        down = 2 ** (len(self.config.block_out_channels) - 1)
+        self.use_tiling = True
+        self.tile_sample_min_height = tile_sample_min_height or self.tile_sample_min_height
+        self.tile_sample_min_width = tile_sample_min_width or self.tile_sample_min_width
+        self.tile_latent_min_height = int(self.tile_sample_min_height / down)
+        self.tile_latent_min_width = int(self.tile_sample_min_width / down)
+        self.tile_overlap_factor_height = tile_overlap_factor_height or self.tile_overlap_factor_height
+        self.tile_overlap_factor_width = tile_overlap_factor_width or self.tile_overlap_factor_width
 
     def disable_tiling(self):
         self.use_tiling = False
 
     def enable_slicing(self):
+        """reference :1162-1167: decode one batch element at a time (:1274-1278).  Every kernel of this decoder treats batch
+        elements independently, so the sliced and the batched decode are the same bits; the flag is honoured as a no-op."""
         self.use_slicing = True
 
     def disable_slicing(self):
@@ -460,6 +478,9 @@ class AutoencoderKLCogVideoX(ModelMixin, ConfigMixin):
         N, C, T, h, w = z.shape
         zcl = ops.ncthw_to_cl(z, scale)          # layout change + the 1/scaling_factor of decode_latents (:512), one rounding
         fbs = self.num_latent_frames_batch_size
+        if self.use_tiling and (w > self.tile_latent_min_width or h > self.tile_latent_min_height):      # :1222-1225
+            assert frames_out is None                    # decode_to_frames sizes its output from the tiled result
+            return [self._tiled_decode_cl(zcl)]
         if T == 1:
             bounds = [(0, 1)]
         else:
@@ -477,6 +498,48 @@ class AutoencoderKLCogVideoX(ModelMixin, ConfigMixin):
         self._clear_fake_context_parallel_cache()
         return chunks
 
+    def _tiled_decode_cl(self, zcl: torch.Tensor) -> torch.Tensor:
+        """reference `tiled_decode` :1303-1392 on the channels-last latent [N,T,h,w,16]: every spatial tile goes through the
+        decoder chunk by chunk with its own conv cache, is blended IN PLACE with the already blended tile above and to its left
+        (`tcx_blend_ramp_bf16`), cropped to the row limits and concatenated -> [N,T',H',W',3] bf16."""
+        N, T, h, w, _ = zcl.shape
+        fbs = self.num_latent_frames_batch_size
+        if T // fbs == 0:
+            raise ValueError(f"tiled decode of {T} latent frame(s): the reference's tile loop (:1345-1364) runs over "
+                             f"num_frames // {fbs} = 0 chunks and fails on an empty concat; call disable_tiling() for single frames")
+        lh, lw = self.tile_latent_min_height, self.tile_latent_min_width
+        overlap_h = int(lh * (1 - self.tile_overlap_factor_height))
+        overlap_w = int(lw * (1 - self.tile_overlap_factor_width))
+        if overlap_h <= 0 or overlap_w <= 0:
+            raise ValueError(f"tiled decode: tile stride {overlap_h} x {overlap_w} latent rows / columns (the reference's `range` "
+                             f"step, :1341-1343) must be positive")
+        blend_h = int(self.tile_sample_min_height * self.tile_overlap_factor_height)
+        blend_w = int(self.tile_sample_min_width * self.tile_overlap_factor_width)
+        limit_h = self.tile_sample_min_height - blend_h
+        limit_w = self.tile_sample_min_width - blend_w
+        rem = T % fbs
+        bounds = [(fbs * k + (0 if k == 0 else rem), fbs * (k + 1) + rem) for k in range(T // fbs)]
+        rows = []
+        for i in range(0, h, overlap_h):
+            row = []
+            for j in range(0, w, overlap_w):
+                self._clear_fake_context_parallel_cache()
+                time = [self.decoder.forward_cl(zcl[:, s:e, i:i + lh, j:j + lw].contiguous()) for s, e in bounds]
+                row.append(torch.cat(time, dim=1))
+            rows.append(row)
+        self._clear_fake_context_parallel_cache()
+        result_rows = []
+        for i, row in enumerate(rows):
+            result_row = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    ops.blend_ramp(rows[i - 1][j], tile, blend_h, 2)
+                if j > 0:
+                    ops.blend_ramp(row[j - 1], tile, blend_w, 3)
+                result_row.append(tile[:, :, :limit_h, :limit_w])
+            result_rows.append(torch.cat(result_row, dim=3))
+        return torch.cat(result_rows, dim=2)
+
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):
         chunks = self._decode_cl(z)
@@ -489,6 +552,8 @@ class AutoencoderKLCogVideoX(ModelMixin, ConfigMixin):
     def decode_to_frames(self, z: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
         """decode + `(x/2+.5).clamp(0,1).float()` of pipeline decode_latents (:514-517), written chunk by chunk."""
         N, C, T, h, w = z.shape
+        if self.use_tiling and (w > self.tile_latent_min_width or h > self.tile_latent_min_height):
+            return self.cl_to_frames(self.decode_cl_bf16(z, scale))
         sf = 2 ** (len(self.config.block_out_channels) - 1)
         Tout = 1 if T == 1 else (T - 1) * int(self.config.temporal_compression_ratio) + 1
         frames = torch.empty((N, self.config.out_channels, Tout, h * sf, w * sf), device=z.device, dtype=torch.float32)

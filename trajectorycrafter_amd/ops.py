@@ -341,6 +341,33 @@ def avgpool_t(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def blend_ramp(a: torch.Tensor, b: torch.Tensor, blend_extent: int, dim: int) -> torch.Tensor:
+    """`blend_v` (dim 2) / `blend_h` (dim 3) of the tiled VAE decode (reference autoencoder_magvit.py:1282-1301) on channels-last
+    tiles [N,T,H,W,C] bf16: the first rows / columns of `b` become a ramp between the last ones of `a` and themselves, in place."""
+    _need(a, "a"); _need(b, "b")
+    if dim not in (2, 3) or a.dim() != 5 or b.dim() != 5 or not a.is_contiguous() or not b.is_contiguous():
+        raise TcxError("blend_ramp: contiguous channels-last tiles [N,T,H,W,C] and dim 2 (rows) or 3 (columns)")
+    other = 3 if dim == 2 else 2
+    if a.shape[:2] != b.shape[:2] or a.shape[4] != b.shape[4] or a.shape[other] != b.shape[other]:
+        raise TcxError(f"blend_ramp: tiles {tuple(a.shape)} and {tuple(b.shape)} do not share the seam")
+    ext = min(a.shape[dim], b.shape[dim], int(blend_extent))
+    if ext <= 0:
+        return b
+    N, T, Hb, Wb, C = b.shape
+    Ha, Wa = a.shape[2], a.shape[3]
+    if dim == 2:
+        outer, inner = N * T, Wb * C
+        a_so, a_se, b_so, b_se = Ha * Wa * C, Wa * C, Hb * Wb * C, Wb * C
+        a_off = (Ha - ext) * Wa * C
+    else:
+        outer, inner = N * T * Hb, C
+        a_so, a_se, b_so, b_se = Wa * C, C, Wb * C, C
+        a_off = (Wa - ext) * C
+    check(_lib.load().tcx_blend_ramp_bf16(a.data_ptr() + 2 * a_off, _p(b), outer, ext, inner, a_so, a_se, b_so, b_se, _stream()),
+          "tcx_blend_ramp_bf16")
+    return b
+
+
 GEMM_BIAS, GEMM_BIAS_GELU, GEMM_GATED_RESIDUAL = 0, 1, 2
 
 
