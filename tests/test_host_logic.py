@@ -182,8 +182,14 @@ def test_config_and_state_dict_round_trip(tmp_path):
         m.set_attn_processor({"x": 1})
     v = AutoencoderKLCogVideoX(block_out_channels=(8, 16, 16, 32), norm_num_groups=4, layers_per_block=1)
     assert v.config.scaling_factor == 1.15258426 and list(v.config.block_out_channels) == [8, 16, 16, 32]
-    with pytest.raises(NotImplementedError):
-        v.enable_tiling()
+    # tile geometry as the reference derives it (:1081-1098, 1109-1153): half the sample size, /8 in latent rows / columns
+    assert (v.tile_sample_min_height, v.tile_sample_min_width, v.tile_latent_min_height, v.tile_latent_min_width) == (240, 360, 30, 45)
+    assert not v.use_tiling and (v.tile_overlap_factor_height, v.tile_overlap_factor_width) == (1 / 6, 1 / 5)
+    v.enable_tiling(tile_sample_min_height=96, tile_overlap_factor_width=0.25)
+    assert v.use_tiling and (v.tile_sample_min_height, v.tile_latent_min_height, v.tile_sample_min_width) == (96, 12, 360)
+    assert (v.tile_overlap_factor_height, v.tile_overlap_factor_width) == (1 / 6, 0.25)
+    v.disable_tiling()
+    assert not v.use_tiling
 
 
 def test_loaders_report_and_refuse_incomplete_checkpoints(tmp_path, capsys):
