@@ -112,6 +112,39 @@ def get_3d_rotary_pos_embed(embed_dim: int, crops_coords, grid_size, temporal_si
     return freqs.cos().contiguous(), freqs.sin().contiguous()
 
 
+def get_1d_sincos_pos_embed_from_grid(embed_dim: int, pos: np.ndarray) -> np.ndarray:
+    """diffusers `get_1d_sincos_pos_embed_from_grid`: [sin(pos w_i) | cos(pos w_i)], w_i = 10000^(-i / (embed_dim/2)), float64."""
+    omega = np.arange(embed_dim // 2, dtype=np.float64)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def get_3d_sincos_pos_embed(embed_dim: int, spatial_size, temporal_size: int, spatial_interpolation_scale: float = 1.0,
+                            temporal_interpolation_scale: float = 1.0) -> np.ndarray:
+    """diffusers `get_3d_sincos_pos_embed` (numpy version, the one the reference's `torch.from_numpy` at crosstransformer3d.py:516-523
+    implies) -> [T, H*W, embed_dim]: a quarter of the channels encode the frame, three quarters the (h | w) position.  The caller
+    passes spatial_size = (post_patch_width, post_patch_height) (:518).  PARITY UNPINNED: diffusers is absent offline."""
+    if embed_dim % 4 != 0:
+        raise ValueError("`embed_dim` must be divisible by 4")
+    if isinstance(spatial_size, int):
+        spatial_size = (spatial_size, spatial_size)
+    dim_spatial, dim_temporal = 3 * embed_dim // 4, embed_dim // 4
+    grid_h = np.arange(spatial_size[1], dtype=np.float32) / spatial_interpolation_scale
+    grid_w = np.arange(spatial_size[0], dtype=np.float32) / spatial_interpolation_scale
+    grid = np.stack(np.meshgrid(grid_w, grid_h), axis=0)                 # w first
+    grid = grid.reshape([2, 1, spatial_size[1], spatial_size[0]])
+    emb_h = get_1d_sincos_pos_embed_from_grid(dim_spatial // 2, grid[0])
+    emb_w = get_1d_sincos_pos_embed_from_grid(dim_spatial // 2, grid[1])
+    pos_spatial = np.concatenate([emb_h, emb_w], axis=1)                 # [H*W, 3D/4]
+    grid_t = np.arange(temporal_size, dtype=np.float32) / temporal_interpolation_scale
+    pos_temporal = get_1d_sincos_pos_embed_from_grid(dim_temporal, grid_t)
+    pos_spatial = np.repeat(pos_spatial[np.newaxis], temporal_size, axis=0)
+    pos_temporal = np.repeat(pos_temporal[:, np.newaxis], spatial_size[0] * spatial_size[1], axis=1)
+    return np.concatenate([pos_temporal, pos_spatial], axis=-1)
+
+
 def apply_rotary_emb(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
     """diffusers `apply_rotary_emb(x, (cos, sin), use_real=True, use_real_unbind_dim=-1)`; x [B,H,S,D] fp32."""
     cos = cos[None, None]

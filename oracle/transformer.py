@@ -83,6 +83,23 @@ def cogvideox_block(p: Prec, sd: dict, prefix: str, hidden, encoder, temb, rotar
     return hidden, encoder
 
 
+def sincos_position_table(p: Prec, cfg: dict, D: int, H: int, W: int, rows: int) -> torch.Tensor:
+    """The `pos_embedding` buffer (reference :516-528: zeros for `max_text_seq_length` rows, then the 3-D sincos table of the
+    CONFIGURED sample size, cast with the model, p.R) resized to the call's latent size as the forward does (:755-782): viewed
+    [1, T_post, H_post, W_post, D] from row `text_seq_length` on, trilinear (align_corners False) to [T_post, H/p, W/p], cut to
+    `rows`.  Like the reference this needs text_seq_length == max_text_seq_length for the view to fit."""
+    patch = cfg["patch_size"]
+    ph, pw = cfg["sample_height"] // patch, cfg["sample_width"] // patch
+    pt = (cfg["sample_frames"] - 1) // cfg["temporal_compression_ratio"] + 1
+    tab = dr.get_3d_sincos_pos_embed(D, (pw, ph), pt, cfg["spatial_interpolation_scale"], cfg["temporal_interpolation_scale"])
+    tab = p.R(torch.from_numpy(tab).flatten(0, 1).float())                      # the buffer is fp32, then model.to(dtype)
+    v = tab.view(1, pt, ph, pw, D).permute(0, 4, 1, 2, 3)
+    v = p.R(torch.nn.functional.interpolate(v, size=[pt, H // patch, W // patch], mode="trilinear", align_corners=False))
+    v = v.permute(0, 2, 3, 4, 1).reshape(1, -1, D)
+    text = torch.zeros(1, cfg["max_text_seq_length"], D)
+    return torch.cat([text, v], dim=1)[:, :rows]
+
+
 def transformer_forward(sd: dict, config: dict, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor,
                         timestep: torch.Tensor, inpaint_latents: torch.Tensor, cross_latents: Optional[torch.Tensor],
                         image_rotary_emb: Optional[Tuple[torch.Tensor, torch.Tensor]], prec: str = "fp32",
@@ -96,8 +113,6 @@ def transformer_forward(sd: dict, config: dict, hidden_states: torch.Tensor, enc
     patch = cfg["patch_size"]
     eps = cfg["norm_eps"]
     B, Fr, C, H, W = hidden_states.shape
-    if not cfg["use_rotary_positional_embeddings"]:
-        raise NotImplementedError("oracle covers the rotary (5B) model only; reference :752-784 is the 2B branch")
     if inpaint_latents is None:
         raise ValueError("inpaint_latents is required (reference :736 concatenates it unconditionally)")
 
@@ -124,6 +139,13 @@ def transformer_forward(sd: dict, config: dict, hidden_states: torch.Tensor, enc
                                   p.R(cross_latents), patch)
     if taps is not None:
         taps["patch_embed"] = hidden.clone()
+
+    # 3. position embedding of the non-rotary (2B) model (:752-784); text rows get zeros
+    if not cfg["use_rotary_positional_embeddings"]:
+        text_len = encoder.shape[1]
+        pos = sincos_position_table(p, cfg, D, H, W, text_len + H * W * Fr // patch ** 2).to(hidden.device)
+        joint = p.R(torch.cat([encoder, hidden], dim=1) + pos)
+        encoder, hidden = joint[:, :text_len], joint[:, text_len:]
 
     rotary = None
     if image_rotary_emb is not None:

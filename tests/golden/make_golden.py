@@ -288,7 +288,7 @@ def install_scaffolding():
     _mod("diffusers.models.attention_processor", AttentionProcessor=object,
          CogVideoXAttnProcessor2_0=CogVideoXAttnProcessor2_0, FusedCogVideoXAttnProcessor2_0=CogVideoXAttnProcessor2_0)
     _mod("diffusers.models.embeddings", TimestepEmbedding=TimestepEmbedding, Timesteps=Timesteps,
-         get_3d_sincos_pos_embed=lambda d, hw, t, *a, **k: np.zeros((t, hw[0] * hw[1], d), dtype=np.float32),
+         get_3d_sincos_pos_embed=dr.get_3d_sincos_pos_embed,
          get_3d_rotary_pos_embed=lambda embed_dim, crops_coords, grid_size, temporal_size, use_real=True:
          dr.get_3d_rotary_pos_embed(embed_dim, crops_coords, grid_size, temporal_size))
     _mod("diffusers.models.modeling_outputs", Transformer2DModelOutput=_Out,
@@ -521,9 +521,43 @@ def make_tiled():
               source="reference AutoencoderKLCogVideoX.enable_tiling() / .decode (tiled_decode, blend_v, blend_h)"))
 
 
+def make_sincos():
+    """transformer_sincos_tiny.safetensors: the reference's NON-rotary branch (crosstransformer3d.py:752-784, the 2B model's
+    position embedding: the `pos_embedding` buffer resized trilinearly to the call's latent size and added to the joint
+    sequence) on TINY_TR with use_rotary_positional_embeddings=False — once at the configured sample size and once at a smaller
+    latent with fewer frames (interpolation + row cut).  Weights are those of transformer_tiny.safetensors.  The buffer itself
+    comes from oracle/diffusers_restated.get_3d_sincos_pos_embed (diffusers is absent): the branch is pinned, the table is not."""
+    if not os.path.isdir(REF):
+        raise SystemExit("make_golden.py needs /root/reference (build container only)")
+    install_scaffolding()
+    sys.path.insert(0, REF)
+    from models.crosstransformer3d import CrossTransformer3DModel
+    cfg = dict(TINY_TR, use_rotary_positional_embeddings=False)
+    tr_sd = bf16_round(iw.random_state_dict(iw.transformer_param_shapes(TINY_TR), seed=0))
+    model = CrossTransformer3DModel(**cfg).eval()
+    print("transformer load:", model.load_state_dict(tr_sd, strict=True))
+    g = torch.Generator().manual_seed(4321)
+    out = {"pos_embedding": model.pos_embedding.clone()}
+    for tag, (T, h, w) in (("a", (3, 8, 12)), ("b", (2, 6, 10))):
+        hs = torch.randn(2, T, 16, h, w, generator=g)
+        enc = torch.randn(2, 10, 32, generator=g)
+        inp = torch.randn(2, T, 17, h, w, generator=g)
+        cross = torch.randn(2, 2, 16, h, w, generator=g)
+        ts = torch.tensor([541, 541])
+        with torch.no_grad():
+            o = model(hs, enc, ts, inpaint_latents=inp, cross_latents=cross, image_rotary_emb=None, return_dict=False)[0]
+        out.update({f"hidden_states_{tag}": hs, f"encoder_hidden_states_{tag}": enc, f"inpaint_latents_{tag}": inp,
+                    f"cross_latents_{tag}": cross, f"timestep_{tag}": ts, f"out_sample_{tag}": o})
+    save("transformer_sincos_tiny.safetensors", out,
+         dict(config=repr(cfg), weights="transformer_tiny.safetensors",
+              source="reference CrossTransformer3DModel.forward, use_rotary_positional_embeddings=False, image_rotary_emb=None"))
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["tiled"]:
         make_tiled()
+    elif sys.argv[1:] == ["sincos"]:
+        make_sincos()
     elif sys.argv[1:] == ["warp"]:
         make_warp()
     elif sys.argv[1:] == ["poses"]:
@@ -533,3 +567,4 @@ if __name__ == "__main__":
         make_warp()
         make_poses()
         make_tiled()
+        make_sincos()

@@ -331,6 +331,31 @@ def test_two_block_transformer_forward_fullsize_vs_oracle(gpu, rotary):
     _check_deep(got, con, ex, "full-size 2-block CrossTransformer3DModel.forward")
 
 
+def test_two_block_2b_width_sincos_forward_fullsize_vs_oracle(gpu):
+    """The NON-rotary model family (CogVideoX-Fun-2B geometry: 30 heads x 64 = 1920 wide, sincos position table added to the
+    joint sequence, reference :752-784; no RoPE in the attention processor) at the configs[2] input shapes with num_layers = 2:
+    GEMMs with N = 1920 / 5760 / 7680, LayerNorm rows of 1920, 30-head attention, `tcx_gated_residual` for the table."""
+    from trajectorycrafter_amd import init_weights as iw
+    from trajectorycrafter_amd.models.crosstransformer3d import CrossTransformer3DModel
+    cfg = dict(iw.TRANSFORMER_5B, num_attention_heads=30, num_layers=2, use_rotary_positional_embeddings=False)
+    sd32 = iw.random_state_dict(iw.transformer_param_shapes(dict(otr.DEFAULT_CONFIG, **cfg)), seed=5, dtype=torch.float32, device=gpu)
+    sd32 = {k: v.to(BF).float() for k, v in sd32.items()}
+    model = CrossTransformer3DModel(**cfg)
+    model.load_state_dict({k: v.cpu() for k, v in sd32.items()}, strict=True)
+    model = model.to(gpu, BF).eval()
+    assert model.pos_embedding.shape == (1, 226 + 17550, 1920) and model.pos_embedding.dtype == BF
+    g = torch.Generator(device=gpu).manual_seed(9)
+    rn = lambda *s: torch.randn(*s, device=gpu, dtype=BF, generator=g)
+    hs, txt, inp, cross = rn(2, 13, 16, 60, 90), rn(2, 226, 4096), rn(2, 13, 17, 60, 90), rn(2, 3, 16, 60, 90)
+    ts = torch.tensor([999, 999], device=gpu)
+    with torch.no_grad():
+        got = model(hs, txt, ts, inpaint_latents=inp, cross_latents=cross, image_rotary_emb=None, return_dict=False)[0]
+        con = otr.transformer_forward(sd32, cfg, hs.float(), txt.float(), ts, inp.float(), cross.float(), None, prec="bf16")
+        ex = otr.transformer_forward(sd32, cfg, hs.float(), txt.float(), ts, inp.float(), cross.float(), None, prec="fp32")
+    assert got.shape == (2, 13, 16, 60, 90) and got.dtype == BF
+    _check_deep(got, con, ex, "full-size 2-block non-rotary (2B width) CrossTransformer3DModel.forward")
+
+
 def test_reference_default_resolution_384x672_full_model(gpu):
     """The reference's own default sample size (demo.py / inference.py `--sample_size 384 672`; fractional RoPE grid positions,
     SURVEY §8a row a8; S = 13 330 tokens, 53 q-blocks, 48 x 84 latents): the 42-layer model, 2 steps + decode, finite, in [0, 1],

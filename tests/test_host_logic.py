@@ -337,3 +337,29 @@ def test_warper_and_driver_need_a_gpu():
         w.forward_warp(f, None, d, eye, eye, k, None, False, twice=False)
     with pytest.raises(NotImplementedError):
         Warper(device="cuda:0").forward_warp(f, None, d, eye, eye, k, None, False, twice=True)
+
+
+def test_sincos_table_and_position_rows_match_oracle():
+    """Product `get_3d_sincos_pos_embed` == the oracle's restatement at fp32; the rows the non-rotary model adds
+    (`CrossTransformer3DModel._position_rows`: buffer in bf16 -> trilinear resize -> cut) == oracle.transformer.sincos_position_table
+    under the bf16 contract, at the configured size (identity resize) and at a smaller latent with fewer frames."""
+    from oracle import transformer as otr
+    from trajectorycrafter_amd.models.crosstransformer3d import get_3d_sincos_pos_embed
+    for D, sz, T, ss, ts in ((128, (6, 4), 3, 1.875, 1.0), (1920, (45, 30), 2, 1.875, 1.0), (64, (5, 7), 2, 1.0, 2.0)):
+        a = torch.from_numpy(dr.get_3d_sincos_pos_embed(D, sz, T, ss, ts)).float()
+        assert torch.equal(get_3d_sincos_pos_embed(D, sz, T, ss, ts).float(), a)
+    cfg = dict(num_attention_heads=2, num_layers=1, in_channels=33, text_embed_dim=32, time_embed_dim=32, max_text_seq_length=10,
+               sample_width=12, sample_height=8, sample_frames=9, use_rotary_positional_embeddings=False)
+    m = CrossTransformer3DModel(**cfg)
+    assert m.pos_embedding.shape == (1, 10 + 3 * 4 * 6, 128) and "pos_embedding" not in m.state_dict()
+    assert float(m.pos_embedding[:, :10].abs().max()) == 0
+    m = m.to(torch.bfloat16)
+    ocfg = dict(otr.DEFAULT_CONFIG)
+    ocfg.update(cfg)
+    for Tn, h, w in ((3, 8, 12), (2, 6, 10), (3, 16, 8)):
+        rows = m._position_rows(10, Tn, h, w, torch.device("cpu"))
+        want = otr.sincos_position_table(Prec("bf16"), ocfg, 128, h, w, 10 + Tn * h * w // 4)
+        assert rows.dtype == torch.bfloat16 and rows.shape == want.shape and torch.equal(rows.float(), want), (Tn, h, w)
+    with pytest.raises(ValueError, match="max_text_seq_length"):
+        m._position_rows(7, 3, 8, 12, torch.device("cpu"))
+    assert not hasattr(CrossTransformer3DModel(**dict(cfg, use_rotary_positional_embeddings=True)), "pos_embedding")

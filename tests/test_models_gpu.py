@@ -120,6 +120,28 @@ def test_transformer_forward_tiny(golden, gpu):
         model._cross_kv_cache = None
 
 
+def test_transformer_sincos_branch_tiny(golden, gpu):
+    """use_rotary_positional_embeddings=False (the 2B family, reference :752-784): the HIP forward against the reference's own run
+    of that branch (fixture) and the oracle's bf16 contract — at the configured sample size and at a smaller latent with fewer
+    frames (trilinear resize of the table + row cut)."""
+    from trajectorycrafter_amd.models.crosstransformer3d import CrossTransformer3DModel
+    t, meta = golden("transformer_sincos_tiny.safetensors")
+    tw, _ = golden(meta["weights"])
+    cfg = ast.literal_eval(meta["config"])
+    sd = _weights(tw)
+    model = CrossTransformer3DModel(**cfg)
+    model.load_state_dict(sd, strict=True)
+    assert torch.equal(model.pos_embedding, t["pos_embedding"])
+    model = model.to(gpu, BF).eval()
+    sdf = {k: v.float() for k, v in sd.items()}
+    for tag in "ab":
+        args = [t[f"{n}_{tag}"] for n in ("hidden_states", "encoder_hidden_states", "timestep", "inpaint_latents", "cross_latents")]
+        out = model(args[0].to(gpu, BF), args[1].to(gpu, BF), args[2].to(gpu), inpaint_latents=args[3].to(gpu, BF),
+                    cross_latents=args[4].to(gpu, BF), image_rotary_emb=None, return_dict=False)[0]
+        ref = otr.transformer_forward(sdf, cfg, *args, None, prec="bf16")
+        _check_deep(out, ref, t[f"out_sample_{tag}"], f"non-rotary transformer tiny ({tag})")
+
+
 def test_transformer_block_and_cross_attention_signatures(golden, gpu):
     """The reference's per-module call signatures work on the mirror classes (CogVideoXBlock :224-230,
     PerceiverCrossAttention :376)."""

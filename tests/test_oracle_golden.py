@@ -52,6 +52,24 @@ def test_transformer_components_match_reference(golden):
     _close(ca, t["tap_cross0"])
 
 
+def test_transformer_sincos_branch_matches_reference(golden):
+    """The non-rotary (2B) position-embedding branch (crosstransformer3d.py:752-784) run by the reference itself: at the configured
+    sample size and at a smaller latent with fewer frames (trilinear resize + row cut).  The sincos table is the oracle's
+    restatement of diffusers' (absent offline: that part is parity-unpinned, KAT in test_oracle_kat.py)."""
+    t, meta = golden("transformer_sincos_tiny.safetensors")
+    tw, _ = golden(meta["weights"])
+    cfg = ast.literal_eval(meta["config"])
+    assert cfg["use_rotary_positional_embeddings"] is False
+    sd = _weights(tw)
+    for tag in "ab":
+        out = otr.transformer_forward(sd, cfg, t[f"hidden_states_{tag}"], t[f"encoder_hidden_states_{tag}"], t[f"timestep_{tag}"],
+                                      t[f"inpaint_latents_{tag}"], t[f"cross_latents_{tag}"], None)
+        _close(out, t[f"out_sample_{tag}"])
+    rot = otr.transformer_forward(sd, dict(cfg, use_rotary_positional_embeddings=True), t["hidden_states_a"], t["encoder_hidden_states_a"],
+                                  t["timestep_a"], t["inpaint_latents_a"], t["cross_latents_a"], None)
+    assert not torch.allclose(rot, t["out_sample_a"], atol=1e-2)                   # the table matters
+
+
 def test_vae_decode_encode_match_reference(golden):
     t, meta = golden("vae_tiny.safetensors")
     cfg = ast.literal_eval(meta["config"])

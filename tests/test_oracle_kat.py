@@ -228,3 +228,34 @@ def test_forward_warp_identity_and_occlusion():
     out, mask, wd, _ = warp.forward_warp(frame, None, near, eye, t2, k)
     torch.testing.assert_close(out[..., 4], frame[..., 2], rtol=0, atol=1e-4)      # far column 3 also lands there, loses
     torch.testing.assert_close(wd[..., 4], torch.ones(b, 1, h), rtol=0, atol=1e-4)
+
+
+def test_sincos_position_table_known_answers():
+    """diffusers `get_3d_sincos_pos_embed` restated (oracle/diffusers_restated.py; parity unpinned): analytic entries.  Channel
+    layout [frame D/4 | first spatial half 3D/8 | second 3D/8], each [sin | cos]; row (t, h, w) with w fastest; frequency i of a
+    part of width d is 10000^(-i / (d/2)); positions are divided by the interpolation scales."""
+    import numpy as np
+    import pytest
+    D, W, H, T, ss, ts = 64, 5, 3, 4, 1.875, 2.0
+    tab = dr.get_3d_sincos_pos_embed(D, (W, H), T, ss, ts)
+    assert tab.shape == (T, H * W, D) and tab.dtype == np.float64
+    dt, dsp = D // 4, 3 * D // 4
+    half = dsp // 2
+    t, h, w = 3, 2, 4
+    row = tab[t, h * W + w]
+    # frame part: sin | cos of (t / ts) * omega_i, omega_i = 10000^(-i/(dt/2))
+    om_t = 1.0 / 10000 ** (np.arange(dt // 2) / (dt / 2))
+    np.testing.assert_allclose(row[:dt // 2], np.sin(np.float32(t) / ts * om_t), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(row[dt // 2:dt], np.cos(np.float32(t) / ts * om_t), rtol=0, atol=1e-12)
+    # spatial part: the first half carries the COLUMN coordinate (meshgrid(w, h)[0]), the second the row coordinate
+    om_s = 1.0 / 10000 ** (np.arange(half // 2) / (half / 2))
+    cw, ch = np.float32(w) / np.float32(ss), np.float32(h) / np.float32(ss)
+    np.testing.assert_allclose(row[dt:dt + half // 2], np.sin(cw * om_s), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(row[dt + half // 2:dt + half], np.cos(cw * om_s), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(row[dt + half:dt + half + half // 2], np.sin(ch * om_s), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(row[dt + half + half // 2:], np.cos(ch * om_s), rtol=0, atol=1e-12)
+    # position 0 in every axis: sin = 0, cos = 1
+    z = tab[0, 0]
+    assert np.all(z[:dt // 2] == 0) and np.all(z[dt // 2:dt] == 1) and np.all(z[dt:dt + half // 2] == 0)
+    with pytest.raises(ValueError):
+        dr.get_3d_sincos_pos_embed(66, (2, 2), 1)

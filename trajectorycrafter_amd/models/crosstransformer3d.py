@@ -377,6 +377,33 @@ class TimestepEmbedding(nn.Module):
         return _linear(ops.silu(h), self.linear_2.weight, self.linear_2.bias)
 
 
+def get_3d_sincos_pos_embed(embed_dim: int, spatial_size, temporal_size: int, spatial_interpolation_scale: float = 1.0,
+                            temporal_interpolation_scale: float = 1.0) -> torch.Tensor:
+    """diffusers `get_3d_sincos_pos_embed` as the reference calls it (:516-523) -> float64 [T, H*W, embed_dim].  Channel layout
+    [frame: D/4 | row: 3D/8 | column: 3D/8], each part [sin | cos] over frequencies 10000^(-i / (part/2)); positions divided by the
+    interpolation scales; spatial_size = (width, height), rows of the table run (h, w) with w fastest.  Host code, float64."""
+    if embed_dim % 4 != 0:
+        raise ValueError("`embed_dim` must be divisible by 4")
+    if isinstance(spatial_size, int):
+        spatial_size = (spatial_size, spatial_size)
+    W, H = spatial_size
+
+    def part(dim: int, pos: torch.Tensor) -> torch.Tensor:
+        omega = 1.0 / 10000 ** (torch.arange(dim // 2, dtype=torch.float64) / (dim / 2.0))
+        ang = pos.to(torch.float64)[:, None] * omega[None]
+        return torch.cat([ang.sin(), ang.cos()], dim=1)
+
+    d_sp, d_t = 3 * embed_dim // 4, embed_dim // 4
+    pos_h = torch.arange(H, dtype=torch.float32) / spatial_interpolation_scale
+    pos_w = torch.arange(W, dtype=torch.float32) / spatial_interpolation_scale
+    # diffusers meshgrids (w, h) and hands grid[0] (the COLUMN coordinate) to the first half of the spatial channels
+    first = part(d_sp // 2, pos_w)[None, :, :].expand(H, W, -1)
+    second = part(d_sp // 2, pos_h)[:, None, :].expand(H, W, -1)
+    spatial = torch.cat([first, second], dim=-1).reshape(H * W, d_sp)
+    temporal = part(d_t, torch.arange(temporal_size, dtype=torch.float32) / temporal_interpolation_scale)
+    return torch.cat([temporal[:, None, :].expand(temporal_size, H * W, d_t), spatial[None].expand(temporal_size, H * W, d_sp)], dim=-1)
+
+
 class CrossTransformer3DModel(ModelMixin, ConfigMixin):
     """reference :403-871."""
 
@@ -428,8 +455,15 @@ class CrossTransformer3DModel(ModelMixin, ConfigMixin):
 
         self.patch_embed = CogVideoXPatchEmbed(patch_size, in_channels, inner_dim, text_embed_dim, bias=True)
         self.embedding_dropout = nn.Dropout(dropout)
-        # The reference always builds a (226+N)x3072 fp32 sincos `pos_embedding` buffer (:516-528); it is
-        # non-persistent and unused by the rotary (5B) model -> dropped ("D").
+        # The reference always builds a (226+N) x D fp32 sincos `pos_embedding` buffer (:516-528, non-persistent).  The rotary (5B)
+        # model never reads it -> not built there ("D"); the non-rotary (2B) model adds it (:752-784).
+        if not use_rotary_positional_embeddings:
+            table = get_3d_sincos_pos_embed(inner_dim, (self.post_patch_width, self.post_patch_height),
+                                            self.post_time_compression_frames, spatial_interpolation_scale, temporal_interpolation_scale)
+            pos_embedding = torch.zeros(1, max_text_seq_length + self.num_patches, inner_dim, requires_grad=False)
+            pos_embedding[:, max_text_seq_length:].copy_(table.flatten(0, 1))
+            self.register_buffer("pos_embedding", pos_embedding, persistent=False)
+        self._pos_cache = None
         self.time_proj = Timesteps(inner_dim, flip_sin_to_cos, freq_shift)
         self.time_embedding = TimestepEmbedding(inner_dim, time_embed_dim, timestep_activation_fn)
         self.transformer_blocks = nn.ModuleList([
@@ -505,9 +539,6 @@ class CrossTransformer3DModel(ModelMixin, ConfigMixin):
             raise ValueError("inpaint_latents is required: the reference concatenates it unconditionally (:736)")
         if self.is_train_cross and cross_latents is None:
             raise ValueError("cross_latents is required when is_train_cross=True (:744-745)")
-        if not self.config.use_rotary_positional_embeddings:
-            raise NotImplementedError("only the rotary (CogVideoX-5B) branch is built; the sincos branch (:752-784) "
-                                      "belongs to the 2B model")
         batch_size, num_frames, channels, height, width = hidden_states.shape
         p = self.config.patch_size
         if height % p or width % p:
@@ -528,6 +559,11 @@ class CrossTransformer3DModel(ModelMixin, ConfigMixin):
             cross_kv = self._cached_cross_kv(cross_latents) if self.cache_cross_kv else None
             if cross_kv is None:
                 cross_hidden_states = self.ref_patch_embed(cross_latents.to(BF16))
+
+        # 3. position embedding of the non-rotary model (:752-784): x += resized table, text rows += 0
+        if not self.config.use_rotary_positional_embeddings:
+            pos = self._position_rows(text_len, num_frames, height, width, x.device)
+            ops.gated_residual_(x, pos.expand(batch_size, -1, -1))
 
         rotary = None
         if image_rotary_emb is not None:
@@ -555,6 +591,26 @@ class CrossTransformer3DModel(ModelMixin, ConfigMixin):
         if not return_dict:
             return (output,)
         return Transformer2DModelOutput(sample=output)
+
+    def _position_rows(self, text_len: int, num_frames: int, height: int, width: int, device) -> torch.Tensor:
+        """The rows the reference adds at :755-783: the `pos_embedding` buffer (in the model's dtype) from row `text_len` on viewed
+        [1, T_post, H_post, W_post, D], resized trilinearly (align_corners False) to [T_post, height/p, width/p], behind the first
+        `text_len` rows, cut to text_len + height*width*num_frames/p^2 rows -> bf16 [1, rows, D].  Table preparation (torch, once per
+        latent size, like the RoPE tables); the per-step add is `tcx_gated_residual`."""
+        key = (text_len, num_frames, height, width, str(device), self.pos_embedding.data_ptr(), self.pos_embedding._version)
+        if self._pos_cache is None or self._pos_cache[0] != key:
+            p, D = self.config.patch_size, self.pos_embedding.shape[-1]
+            pt, ph, pw = self.post_time_compression_frames, self.post_patch_height, self.post_patch_width
+            buf = self.pos_embedding.to(device)
+            if buf.shape[1] - text_len != pt * ph * pw:
+                raise ValueError(f"non-rotary position embedding: the reference's view (:759-765) needs text_seq_length == "
+                                 f"max_text_seq_length ({self.config.max_text_seq_length}), got {text_len}")
+            grid = buf[:, text_len:].view(1, pt, ph, pw, D).permute(0, 4, 1, 2, 3)
+            grid = F.interpolate(grid, size=[pt, height // p, width // p], mode="trilinear", align_corners=False)
+            rows = torch.cat([buf[:, :text_len], grid.permute(0, 2, 3, 4, 1).reshape(1, -1, D)], dim=1)
+            rows = rows[:, : text_len + height * width * num_frames // (p * p)].to(BF16).contiguous()
+            self._pos_cache = (key, rows)
+        return self._pos_cache[1]
 
     # ---- opt-in: reuse of the reference-token K / V across denoising steps ----
     # `to_kv(norm1(ref_patch_embed(cross_latents)))` (+ the k scaling) of the 21 cross-attention layers is a function of the
