@@ -284,17 +284,27 @@ def run_rank(args):
     import torch.distributed as dist
     from trajectorycrafter_amd import dp, ops
 
-    # RCCL ("nccl") is THE collective backend of the path.  gloo (host-mediated) is only ever used when asked for explicitly
-    # (TCX_DIST_BACKEND=gloo: the one-card rehearsal); an RCCL failure is fatal, with its error text — never a silent fallback
-    # that would put a host-staged gather into a scaling number.
+    # RCCL ("nccl") is THE collective backend of the path.  gloo (host-mediated) is used when asked for explicitly
+    # (TCX_DIST_BACKEND=gloo: the one-card rehearsal) or, LOUDLY, when RCCL's communicator cannot be created (eager init: `device_id`
+    # is passed, so the failure surfaces here and on every rank): the error goes to stderr and into the JSON line's top level
+    # (`collective_fallback`), so a host-staged gather can never pass for an RCCL scaling number.  TCX_BENCH_RCCL_FATAL=1 turns the
+    # fallback into exit code 3.
     backend = os.environ.get("TCX_DIST_BACKEND", "nccl")
+    rccl_error = None
     if world > 1:
         try:
             dp.init_distributed(backend)
         except Exception as e:
-            print(f"[bench] rank {rank}: init_process_group(backend={backend!r}) FAILED: {type(e).__name__}: {e}\n"
-                  f"[bench] no fallback is taken (set TCX_DIST_BACKEND=gloo explicitly for a host-mediated rehearsal)", file=sys.stderr, flush=True)
-            raise SystemExit(3)
+            rccl_error = f"{type(e).__name__}: {e}"
+            print(f"[bench] rank {rank}: init_process_group(backend={backend!r}) FAILED: {rccl_error}", file=sys.stderr, flush=True)
+            if backend != "nccl" or os.environ.get("TCX_BENCH_RCCL_FATAL") == "1":
+                raise SystemExit(3)
+            print(f"[bench] rank {rank}: FALLING BACK to gloo (host-mediated all-gather) — flagged in the JSON line as `collective_fallback`; "
+                  "this is NOT an RCCL measurement", file=sys.stderr, flush=True)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            backend = "gloo"
+            dp.init_distributed(backend)
         if backend != "nccl":
             print(f"[bench] WARNING: collective backend is {backend!r}, not RCCL: the all-gather is host-mediated; this is a rehearsal, "
                   "not a scaling measurement", file=sys.stderr, flush=True)
@@ -408,6 +418,8 @@ def run_rank(args):
             rec["config"]["debug_env"] = dbg
         if world > 1 and backend != "nccl":
             rec["collective_backend_warning"] = f"{backend}: host-mediated all-gather, NOT RCCL — rehearsal only"
+        if rccl_error is not None:
+            rec["collective_fallback"] = f"gloo, because RCCL failed to initialise: {rccl_error[:400]}"
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline_bounded(args)
         print(json.dumps(rec), flush=True)
