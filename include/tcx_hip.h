@@ -188,6 +188,25 @@ int tcx_cfg_ddim_cog_step(const void* u, const void* c, const void* x, void* out
                           float sqrt_alpha_t, float sqrt_beta_t, float coef_sample, float coef_x0, int32_t pred_dtype,
                           void* stream);
 
+/* ---- K10c: the same fusion for the sigma-parametrised samplers of the reference's table (demo.py:647-654: "Euler",
+ * "Euler A", "DPM++" = diffusers EulerDiscreteScheduler / EulerAncestralDiscreteScheduler / DPMSolverMultistepScheduler,
+ * v-prediction).  `coef` is a HOST array of 5 floats: the scheduler's own 0-dim fp32 scalars (scheduler.py computes them with the
+ * library's operation sequence); the kernel applies the library's per-element fp32 operations in their order.
+ *   noise-free guidance v = u + g (c - u) as above;  x = bf16 latents (upcast);  out = bf16r(prev), may alias x.
+ *   TCX_STEP_EULER     coef = {a, sigma^2 + 1, sigma, dt, sigma_up}:  x0 = v a + x / coef[1];  d = (x - x0) / sigma;
+ *                      prev = x + d dt;  with `noise` (fp32, n elements; Euler A): prev += noise sigma_up.  No history.
+ *   TCX_STEP_DPMPP_2M  coef = {alpha_i, sig_i, A, B, 1/r0}:  x0 = bf16r(alpha_i x) - sig_i v, written to `hist_out` (fp32, n);
+ *                      prev = A x - B x0, and with `hist_in` (the previous step's hist_out): prev -= (B/2) ((1/r0)(x0 - hist_in)).
+ * Replaces: models/pipeline_trajectorycrafter.py:1117,1157-1167,1178 with the `step` of the scheduler demo.py:647-657 selects. */
+#define TCX_STEP_EULER 0
+#define TCX_STEP_DPMPP_2M 1
+int tcx_cfg_sigma_step(const void* u, const void* c, const void* x, void* out, int64_t n, float guidance, int32_t kind,
+                       const float* coef, const float* hist_in, float* hist_out, const float* noise, int32_t pred_dtype, void* stream);
+
+/* y = bf16r(x / d), n bf16 elements: `scheduler.scale_model_input` of the Euler samplers (x / sqrt(sigma^2 + 1); a bf16 tensor
+ * divided by a 0-dim fp32 tensor stays bf16).  Replaces: models/pipeline_trajectorycrafter.py:1099-1101 for those schedulers. */
+int tcx_div_bf16(const void* x, void* y, int64_t n, float d, void* stream);
+
 /* ---- K11 / K12 / 1x1x1 convs: bf16 implicit-GEMM convolution, channels-last -------------------
  * y[n, t, oy, ox, co] = bias[co] + sum_{dt,dy,dx,ci} X(t + dt, oy*stride + dy - pad_h, ox*stride + dx - pad_w, ci)
  *                                                    * w[co, dt, dy, dx, ci]   (+ res[n,t,oy,ox,co])

@@ -361,7 +361,7 @@ class DDIMScheduler:
             raise ValueError(self.timestep_spacing)
         self.timesteps = torch.from_numpy(ts)
 
-    def scale_model_input(self, sample, timestep=None):
+    def scale_model_input(self, p: Prec, sample, timestep=None):
         return sample
 
     def coeffs(self, timestep: int):
@@ -446,3 +446,175 @@ class CogVideoXDDIMScheduler(DDIMScheduler):
         a = ((1 - a_prev) / (1 - a_t)) ** 0.5
         b = a_prev ** 0.5 - a_t ** 0.5 * a
         return p.R(f(a) * s) + f(b) * x0
+
+
+# ---------------------------------------------------------------------------
+# sigma-parametrised samplers of the reference's table (demo.py:647-654: "Euler", "Euler A", "DPM++"), restated from the
+# published diffusers algorithms (>= 0.30.1, requirements.txt:26).  PARITY UNPINNED: diffusers is absent offline; pinned only by
+# the analytic known-answer tests in tests/test_oracle_kat.py.  `from_pretrained(model, subfolder="scheduler")` hands them the
+# CogVideoX scheduler_config.json: scaled_linear betas 0.00085..0.012, v_prediction, trailing spacing, zero-terminal-SNR rescale
+# (these classes then set alphas_cumprod[-1] = 2^-24 so that sigma stays finite: sigma_max = 4096); keys they do not know
+# (snr_shift_scale, set_alpha_to_one, clip_sample ...) are ignored.  Class defaults otherwise: linear sigma interpolation, no
+# Karras sigmas, final sigma 0, discrete timesteps, DPM-Solver++ 2M midpoint with lower_order_final.
+# Every coefficient is a 0-dim fp32 torch tensor computed by the same operation sequence as the library's, so that the
+# per-element arithmetic (fp32 mul / div / add, no contraction) can be reproduced bit for bit by the HIP step kernel.
+# ---------------------------------------------------------------------------
+class _SigmaScheduler:
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 prediction_type="v_prediction", timestep_spacing="trailing", rescale_betas_zero_snr=True, steps_offset=0, **ignored):
+        assert beta_schedule == "scaled_linear" and prediction_type == "v_prediction"
+        self.num_train_timesteps, self.timestep_spacing, self.steps_offset = num_train_timesteps, timestep_spacing, steps_offset
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        if rescale_betas_zero_snr:
+            alphas = 1.0 - betas
+            abar_sqrt = torch.cumprod(alphas, dim=0).sqrt()
+            a0, aT = abar_sqrt[0].clone(), abar_sqrt[-1].clone()
+            abar_sqrt = (abar_sqrt - aT) * (a0 / (a0 - aT))
+            abar = abar_sqrt ** 2
+            alphas = torch.cat([abar[0:1], abar[1:] / abar[:-1]])
+            betas = 1 - alphas
+        self.betas = betas
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        if rescale_betas_zero_snr:
+            self.alphas_cumprod[-1] = 2 ** -24               # "close to 0 without being 0 so the first sigma is not inf"
+        self.sigmas = None
+        self.timesteps = None
+        self.num_inference_steps = None
+
+    def _grid(self, n: int) -> np.ndarray:
+        N = self.num_train_timesteps
+        if self.timestep_spacing == "trailing":
+            return np.round(np.arange(N, 0, -N / n)) - 1
+        if self.timestep_spacing == "leading":
+            return (np.arange(0, n) * (N // n)).round()[::-1].copy().astype(np.float64) + self.steps_offset
+        raise ValueError(self.timestep_spacing)
+
+    def _interp_sigmas(self, ts: np.ndarray) -> np.ndarray:
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        return np.interp(ts, np.arange(0, len(sig)), sig)
+
+    def index_for(self, timestep) -> int:
+        idx = (self.timesteps == timestep).nonzero()
+        assert len(idx) == 1, "duplicate timesteps: the library's begin-index rule is not restated"
+        return int(idx[0])
+
+    def scale_model_input(self, p: Prec, sample: torch.Tensor, timestep) -> torch.Tensor:
+        return sample
+
+
+class EulerDiscreteScheduler(_SigmaScheduler):
+    """diffusers `EulerDiscreteScheduler` ("Euler"), s_churn = 0:
+
+        sigma_i from the interpolated table (+ a final 0);  model input = x / sqrt(sigma^2 + 1);  init_noise_sigma = sigma_max
+        x0 = v * (-sigma / sqrt(sigma^2 + 1)) + x / (sigma^2 + 1);   d = (x - x0) / sigma;   x_next = x + d (sigma_next - sigma)
+
+    with x upcast to fp32 first and the result cast to the model output's dtype (fp32 in the reference's loop, :1108-1167)."""
+    ancestral = False
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        ts = self._grid(num_inference_steps).astype(np.float32)
+        sig = np.concatenate([self._interp_sigmas(ts), [0.0]]).astype(np.float32)
+        self.sigmas = torch.from_numpy(sig)
+        self.timesteps = torch.from_numpy(ts)
+
+    @property
+    def init_noise_sigma(self):
+        mx = self.sigmas.max() if self.sigmas is not None else (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).max()
+        return mx if self.timestep_spacing in ("linspace", "trailing") else (mx ** 2 + 1) ** 0.5
+
+    def scale_model_input(self, p: Prec, sample: torch.Tensor, timestep) -> torch.Tensor:
+        sigma = self.sigmas[self.index_for(timestep)]
+        return p.R(sample / ((sigma ** 2 + 1) ** 0.5))       # bf16 tensor / 0-dim fp32 tensor stays bf16
+
+    def step_coeffs(self, timestep):
+        i = self.index_for(timestep)
+        sigma, sigma_to = self.sigmas[i], self.sigmas[i + 1]
+        a = -sigma / (sigma ** 2 + 1) ** 0.5
+        s2p1 = sigma ** 2 + 1
+        if not self.ancestral:
+            return a, s2p1, sigma, sigma_to - sigma, None
+        sigma_up = (sigma_to ** 2 * (sigma ** 2 - sigma_to ** 2) / sigma ** 2) ** 0.5
+        sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+        return a, s2p1, sigma, sigma_down - sigma, sigma_up
+
+    def step(self, p: Prec, model_output: torch.Tensor, timestep, sample: torch.Tensor, noise: Optional[torch.Tensor] = None):
+        a, s2p1, sigma, dt, sigma_up = self.step_coeffs(timestep)
+        s = sample.float()
+        x0 = model_output * a + (s / s2p1)
+        derivative = (s - x0) / sigma
+        prev = s + derivative * dt
+        if self.ancestral:
+            prev = prev + noise * sigma_up
+        return prev
+
+
+class EulerAncestralDiscreteScheduler(EulerDiscreteScheduler):
+    """diffusers `EulerAncestralDiscreteScheduler` ("Euler A"): the Euler step to sigma_down followed by fresh noise of scale
+    sigma_up (sigma_up^2 = sigma_to^2 (sigma^2 - sigma_to^2) / sigma^2, sigma_down^2 = sigma_to^2 - sigma_up^2); the noise is
+    `randn_tensor(model_output.shape, dtype=model_output.dtype, device=..., generator=generator)`, one draw per step."""
+    ancestral = True
+
+
+class DPMSolverMultistepScheduler(_SigmaScheduler):
+    """diffusers `DPMSolverMultistepScheduler` ("DPM++"): algorithm_type dpmsolver++, solver_order 2, midpoint, lower_order_final,
+    final sigma 0, init_noise_sigma 1, int64 timesteps.  With alpha = 1 / sqrt(sigma^2 + 1), sig = sigma alpha, lambda = log alpha - log sig:
+
+        x0_i = alpha_i x - sig_i v                      (alpha_i x is a 0-dim fp32 scalar times the bf16 latents: rounded to bf16)
+        h = lambda_{i+1} - lambda_i;   A = sig_{i+1} / sig_i;   B = alpha_{i+1} (exp(-h) - 1)
+        first order:   x_next = A x - B x0_i            (first step; last step because the final sigma is 0)
+        second order:  r0 = (lambda_i - lambda_{i-1}) / h;  D1 = (1 / r0)(x0_i - x0_{i-1});  x_next = A x - B x0_i - 0.5 B D1"""
+
+    init_noise_sigma = 1.0
+    solver_order = 2
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        ts = self._grid(num_inference_steps).astype(np.int64)
+        sig = np.concatenate([self._interp_sigmas(ts), [0.0]]).astype(np.float32)
+        self.sigmas = torch.from_numpy(sig)
+        self.timesteps = torch.from_numpy(ts)
+        self.model_outputs = [None] * self.solver_order
+        self.lower_order_nums = 0
+
+    @staticmethod
+    def _alpha_sigma(sigma):
+        alpha_t = 1 / ((sigma ** 2 + 1) ** 0.5)
+        return alpha_t, sigma * alpha_t
+
+    def step_coeffs(self, timestep):
+        """(alpha_s0, sig_s0, A, B, 1 / r0 or None) as 0-dim fp32 tensors; second order iff 1 / r0 is given."""
+        i = self.index_for(timestep)
+        n = len(self.timesteps)
+        alpha_t, sigma_t = self._alpha_sigma(self.sigmas[i + 1])
+        alpha_s0, sigma_s0 = self._alpha_sigma(self.sigmas[i])
+        lambda_t = torch.log(alpha_t) - torch.log(sigma_t)
+        lambda_s0 = torch.log(alpha_s0) - torch.log(sigma_s0)
+        h = lambda_t - lambda_s0
+        A = sigma_t / sigma_s0
+        B = alpha_t * (torch.exp(-h) - 1.0)
+        lower_order_final = i == n - 1                       # final_sigmas_type == "zero" (or fewer than 15 steps)
+        lower_order_second = i == n - 2 and n < 15           # never taken by a second-order solver; kept for the record
+        if self.lower_order_nums < 1 or lower_order_final:
+            return alpha_s0, sigma_s0, A, B, None
+        alpha_s1, sigma_s1 = self._alpha_sigma(self.sigmas[i - 1])
+        lambda_s1 = torch.log(alpha_s1) - torch.log(sigma_s1)
+        r0 = (lambda_s0 - lambda_s1) / h
+        return alpha_s0, sigma_s0, A, B, 1.0 / r0
+
+    def step(self, p: Prec, model_output: torch.Tensor, timestep, sample: torch.Tensor):
+        alpha_s0, sigma_s0, A, B, inv_r0 = self.step_coeffs(timestep)
+        s = sample.float()
+        x0 = p.R(alpha_s0 * s) - sigma_s0 * model_output     # convert_model_output sees the un-upcast (bf16) sample
+        self.model_outputs = self.model_outputs[1:] + [x0]
+        if inv_r0 is None:
+            prev = A * s - B * x0
+        else:
+            m0, m1 = self.model_outputs[-1], self.model_outputs[-2]
+            D1 = inv_r0 * (m0 - m1)
+            prev = A * s - B * m0 - 0.5 * B * D1
+        if self.lower_order_nums < self.solver_order:
+            self.lower_order_nums += 1
+        return prev

@@ -90,10 +90,13 @@ def build_conditioning(vae_sd, vae_cfg, video, mask_video, reference, height, wi
 def denoise(tr_sd, tr_cfg, latents, prompt_embeds, negative_prompt_embeds, inpaint_latents, ref_input,
             height, width, num_inference_steps=50, guidance_scale=6.0, prec="fp32",
             scheduler: Optional[dr.DDIMScheduler] = None, num_blocks: Optional[int] = None,
-            on_step: Optional[Callable] = None, strength: float = 1.0, video_latents: Optional[torch.Tensor] = None):
+            on_step: Optional[Callable] = None, strength: float = 1.0, video_latents: Optional[torch.Tensor] = None,
+            step_noise: Optional[Callable] = None):
     """reference :1076-1198: the 50-step loop.  `latents` [B,T,16,h,w]; returns latents (activation dtype).
     strength < 1 (:664-671, :431-436): the loop starts `int(steps * strength)` steps before the end; when `video_latents`
-    is given, `latents` is the NOISE and the start point is scheduler.add_noise(video_latents, noise, first timestep)."""
+    is given, `latents` is the NOISE and the start point is scheduler.add_noise(video_latents, noise, first timestep).
+    `scheduler`: any of the restated samplers of demo.py:647-654; the model input goes through `scale_model_input` (:1099-1101);
+    `step_noise(i, shape)` supplies the fp32 noise "Euler A" draws per step (the caller owns the generator semantics)."""
     p = Prec(prec)
     sched = scheduler or dr.DDIMScheduler()
     do_cfg = guidance_scale > 1.0
@@ -107,16 +110,20 @@ def denoise(tr_sd, tr_cfg, latents, prompt_embeds, negative_prompt_embeds, inpai
     if strength < 1.0 and video_latents is not None:
         lat = p.R(sched.add_noise(p, video_latents, latents, int(timesteps[0])))
     else:
-        lat = p.R(latents * sched.init_noise_sigma)
+        lat = p.R(latents * float(sched.init_noise_sigma))
     for i, t in enumerate(timesteps):
         x = torch.cat([lat] * 2) if do_cfg else lat
+        x = sched.scale_model_input(p, x, t)                                                        # :1099-1101
         ts = t.expand(x.shape[0])
         noise_pred = otr.transformer_forward(tr_sd, cfg, x, pe, ts, inpaint_latents.float(), ref_input.float(),
                                              rotary, prec=prec, num_blocks=num_blocks).float()      # :1108-1117
         if do_cfg:
             u, c = noise_pred.chunk(2)
             noise_pred = u + guidance_scale * (c - u)                                               # :1157-1161
-        lat = p.R(sched.step(p, noise_pred, int(t), p.out(lat)))                                    # :1164-1178
+        if getattr(sched, "ancestral", False):
+            lat = p.R(sched.step(p, noise_pred, t, p.out(lat), noise=step_noise(i, lat.shape)))
+        else:
+            lat = p.R(sched.step(p, noise_pred, t if isinstance(sched, dr._SigmaScheduler) else int(t), p.out(lat)))   # :1164-1178
         if on_step is not None:
             on_step(i, int(t), lat)
     return p.out(lat)

@@ -73,9 +73,8 @@ def test_cog_scheduler_matches_oracle_and_sampler_table(tmp_path):
     (d / "scheduler_config.json").write_text(json.dumps({"_class_name": "CogVideoXDDIMScheduler", "snr_shift_scale": 3.0,
                                                          "clip_sample_range": 1.0, "sample_max_value": 1.0, "trained_betas": None}))
     assert make_scheduler("DDIM_Cog", str(tmp_path)).config.snr_shift_scale == 3.0
-    for name in ("Euler", "Euler A", "DPM++", "PNDM"):
-        with pytest.raises(NotImplementedError, match="not built"):
-            make_scheduler(name, None)
+    with pytest.raises(NotImplementedError, match="not built"):
+        make_scheduler("PNDM", None)
     with pytest.raises(ValueError, match="unknown sampler"):
         make_scheduler("LCM", None)
 
@@ -363,3 +362,44 @@ def test_sincos_table_and_position_rows_match_oracle():
     with pytest.raises(ValueError, match="max_text_seq_length"):
         m._position_rows(7, 3, 8, 12, torch.device("cpu"))
     assert not hasattr(CrossTransformer3DModel(**dict(cfg, use_rotary_positional_embeddings=True)), "pos_embedding")
+
+
+def test_sigma_samplers_match_oracle_tables(tmp_path):
+    """"Euler" / "Euler A" / "DPM++" (demo.py:647-654): timesteps (values and dtype), sigma tables, init_noise_sigma and every step's
+    fp32 coefficients of the product schedulers == the oracle's restatement, bit for bit; sampler table + from_pretrained on the
+    CogVideoX scheduler_config.json (unknown keys ignored, like the library)."""
+    from trajectorycrafter_amd import scheduler as S
+    from trajectorycrafter_amd.run import make_scheduler
+    pairs = ((S.EulerDiscreteScheduler, dr.EulerDiscreteScheduler), (S.EulerAncestralDiscreteScheduler, dr.EulerAncestralDiscreteScheduler),
+             (S.DPMSolverMultistepScheduler, dr.DPMSolverMultistepScheduler))
+    for pc, oc in pairs:
+        a, b = pc(), oc()
+        for n in (1, 2, 25, 50):
+            a.set_timesteps(n), b.set_timesteps(n)
+            assert a.timesteps.dtype == b.timesteps.dtype and torch.equal(a.timesteps, b.timesteps) and torch.equal(a.sigmas, b.sigmas)
+            assert float(a.init_noise_sigma) == float(b.init_noise_sigma)
+            for t in a.timesteps.tolist():
+                cb = b.step_coeffs(t)
+                want = [float(v) for v in cb[:4]] + [float(cb[4]) if cb[4] is not None else 0.0]
+                if pc is S.DPMSolverMultistepScheduler:
+                    ca, second = a.step_coeffs(t)
+                    assert ca == want and second == (cb[4] is not None), (n, t)
+                    a._lower_order_nums = min(a._lower_order_nums + 1, 2)
+                    b.lower_order_nums = min(b.lower_order_nums + 1, 2)
+                else:
+                    assert a.step_coeffs(t) == want, (n, t)
+        with pytest.raises(ValueError, match="not on the schedule"):
+            a.step_coeffs(998)
+        with pytest.raises(NotImplementedError, match="add_noise"):
+            a.add_noise(None, None, None)
+    d = tmp_path / "scheduler"
+    d.mkdir()
+    (d / "scheduler_config.json").write_text(json.dumps({"_class_name": "CogVideoXDDIMScheduler", "_diffusers_version": "0.31.0.dev0",
+        "beta_end": 0.012, "beta_schedule": "scaled_linear", "beta_start": 0.00085, "clip_sample": False, "clip_sample_range": 1.0,
+        "num_train_timesteps": 1000, "prediction_type": "v_prediction", "rescale_betas_zero_snr": True, "sample_max_value": 1.0,
+        "set_alpha_to_one": True, "snr_shift_scale": 1.0, "steps_offset": 0, "timestep_spacing": "trailing", "trained_betas": None}))
+    for name, pc in (("Euler", S.EulerDiscreteScheduler), ("Euler A", S.EulerAncestralDiscreteScheduler), ("DPM++", S.DPMSolverMultistepScheduler)):
+        sch = make_scheduler(name, str(tmp_path))
+        assert type(sch) is pc and type(make_scheduler(name, None)) is pc and sch.config.timestep_spacing == "trailing"
+        sch.set_timesteps(50)
+        assert int(sch.timesteps[0]) == 999

@@ -394,6 +394,57 @@ def test_cfg_ddim_cog_step_matches_oracle(ops, t):
     assert_bf16_close(ps.step(dev(bf(u)), t, dev(x))[0], s.step(Prec("bf16"), bf(u).float(), t, x), atol=1e-5)
 
 
+@pytest.mark.parametrize("name", ["Euler", "Euler A", "DPM++"])
+def test_cfg_sigma_step_matches_oracle(ops, name):
+    """`tcx_cfg_sigma_step` (samplers "Euler", "Euler A", "DPM++") through the product schedulers' `fused_cfg_step`, a whole
+    5-step trajectory with CFG 6 on fixed random model outputs, against the oracle's restated diffusers steps under the bf16
+    contract: the kernel applies the library's per-element fp32 operations in their order, so the latents agree to the bit after
+    every step (fp32 predictions); `scale_model_input` = `tcx_div_bf16`, bit-equal as well.  bf16 predictions and the no-guidance
+    form (`step`) ride along."""
+    from trajectorycrafter_amd import scheduler as S
+    pc, oc = {"Euler": (S.EulerDiscreteScheduler, dr.EulerDiscreteScheduler), "Euler A": (S.EulerAncestralDiscreteScheduler,
+              dr.EulerAncestralDiscreteScheduler), "DPM++": (S.DPMSolverMultistepScheduler, dr.DPMSolverMultistepScheduler)}[name]
+    g = torch.Generator().manual_seed(77)
+    p = Prec("bf16")
+    for n_steps, pred_bf16 in ((5, False), (50, False), (3, True)):
+        ps, s = pc(), oc()
+        ps.set_timesteps(n_steps), s.set_timesteps(n_steps)
+        x = bf(torch.randn(1, 5, 16, 6, 10, generator=g) * float(s.init_noise_sigma))
+        xd = dev(x)
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        gen_ref = torch.Generator(device="cuda").manual_seed(5)
+        for i, t in enumerate(s.timesteps[:6]):
+            # scale_model_input
+            want_in = s.scale_model_input(p, x.float(), t)
+            got_in = ps.scale_model_input(xd, t)
+            assert torch.equal(got_in.float().cpu(), want_in), (name, int(t))
+            pred = torch.randn(2, 5, 16, 6, 10, generator=g)
+            if pred_bf16:
+                pred = bf(pred)
+            u, c = pred.float().chunk(2)
+            v = u + 6.0 * (c - u)
+            if s.ancestral if hasattr(s, "ancestral") else False:
+                nz = torch.randn(x.shape, generator=gen_ref, device="cuda", dtype=torch.float32).cpu()
+                ref = p.R(s.step(p, v, t, x, noise=nz))
+            else:
+                ref = p.R(s.step(p, v, t, x))
+            d = dev(pred)
+            got = ps.fused_cfg_step(d[:1], d[1:], xd, 6.0, t, generator=gen)
+            assert got.dtype == torch.bfloat16 and torch.equal(got.float().cpu(), ref), (name, n_steps, i, float((got.float().cpu() - ref).abs().max()))
+            x, xd = ref.to(torch.bfloat16), got
+    # diffusers-shaped `step` (no guidance) == fused form with guidance 1 and no conditional half
+    ps, s = pc(), oc()
+    ps.set_timesteps(4), s.set_timesteps(4)
+    x = bf(torch.randn(1, 3, 16, 4, 6, generator=g))
+    u = torch.randn(1, 3, 16, 4, 6, generator=g)
+    t = s.timesteps[0]
+    kw = dict(noise=torch.randn(x.shape, generator=torch.Generator(device="cuda").manual_seed(9), device="cuda").cpu()) if name == "Euler A" else {}
+    got = ps.step(dev(u), t, dev(x), generator=torch.Generator(device="cuda").manual_seed(9))[0]
+    assert torch.equal(got.float().cpu(), p.R(s.step(p, u, t, x, **kw)))
+    with pytest.raises(ValueError, match="not on the schedule"):
+        ps.fused_cfg_step(dev(u), None, dev(x), 1.0, 998)
+
+
 # ----------------------------------------------------------------------------- VAE kernels
 def to_cl(x):
     return x.permute(0, 2, 3, 4, 1).contiguous()

@@ -259,3 +259,92 @@ def test_sincos_position_table_known_answers():
     assert np.all(z[:dt // 2] == 0) and np.all(z[dt // 2:dt] == 1) and np.all(z[dt:dt + half // 2] == 0)
     with pytest.raises(ValueError):
         dr.get_3d_sincos_pos_embed(66, (2, 2), 1)
+
+
+def test_sigma_sampler_tables_known_answers():
+    """"Euler" / "Euler A" / "DPM++" restated (oracle/diffusers_restated.py; parity unpinned): the sigma table.  sigma = sqrt((1 - abar)
+    / abar) of the zero-SNR-rescaled scaled-linear schedule with abar_T pinned to 2^-24 -> sigma_max = sqrt(2^24 - 1); trailing
+    timesteps 999, 979, ..., 19; a final sigma of 0; Euler starts from noise * sigma_max and feeds x / sqrt(sigma^2 + 1) to the model;
+    DPM++ starts from unit noise and uses int64 timesteps."""
+    import numpy as np
+    for cls in (dr.EulerDiscreteScheduler, dr.EulerAncestralDiscreteScheduler, dr.DPMSolverMultistepScheduler):
+        s = cls()
+        s.set_timesteps(50)
+        assert s.timesteps.tolist() == list(range(999, 0, -20)) and len(s.sigmas) == 51 and float(s.sigmas[-1]) == 0.0
+        assert float(s.sigmas[0]) == float(np.float32(np.sqrt(np.float32(1 - 2.0 ** -24) / np.float32(2.0 ** -24))))
+        assert bool((s.sigmas[:-1] > s.sigmas[1:]).all())
+        abar = dr.DDIMScheduler().alphas_cumprod                       # the same schedule below the last entry
+        np.testing.assert_allclose(float(s.sigmas[1]), float(((1 - abar[979]) / abar[979]) ** 0.5), rtol=1e-6)
+    e, d = dr.EulerDiscreteScheduler(), dr.DPMSolverMultistepScheduler()
+    e.set_timesteps(50), d.set_timesteps(50)
+    assert e.timesteps.dtype == torch.float32 and d.timesteps.dtype == torch.int64
+    assert float(e.init_noise_sigma) == float(e.sigmas[0]) and d.init_noise_sigma == 1.0
+    x = torch.randn(3, 4, generator=torch.Generator().manual_seed(0))
+    torch.testing.assert_close(e.scale_model_input(Prec("fp32"), x, 979.0), x / (float(e.sigmas[1]) ** 2 + 1) ** 0.5, rtol=1e-6, atol=0)
+
+
+def test_euler_step_known_answers():
+    """One Euler step of the probability-flow ODE dx/dsigma = (x - x0) / sigma with an exact v-prediction moves x on the straight
+    line to x0: x_next = x0 + (sigma_next / sigma)(x - x0) (independent float64 evaluation).  "Euler A": sigma_up^2 + sigma_down^2 =
+    sigma_next^2, zero noise = the Euler step to sigma_down, the noise enters with weight sigma_up; the last step lands on x0."""
+    g = torch.Generator().manual_seed(1)
+    x0, eps = torch.randn(5, 7, generator=g), torch.randn(5, 7, generator=g)
+    p = Prec("fp32")
+    for cls in (dr.EulerDiscreteScheduler, dr.EulerAncestralDiscreteScheduler):
+        s = cls()
+        s.set_timesteps(50)
+        for i in (0, 1, 25, 48, 49):
+            t, sg, sg_to = s.timesteps[i], float(s.sigmas[i]), float(s.sigmas[i + 1])
+            x = x0 + sg * eps                                          # the sample at noise level sigma (sigma parametrisation)
+            a = 1 / (sg ** 2 + 1) ** 0.5
+            v = a * eps - sg * a * x0                                  # exact v for the scaled input a x = a x0 + (sg a) eps
+            nz = torch.randn(5, 7, generator=g)
+            got = s.step(p, v.float(), t, x, noise=nz) if s.ancestral else s.step(p, v.float(), t, x)
+            if not s.ancestral:
+                want = x0.double() + (sg_to / sg) * (x.double() - x0.double())
+            else:
+                up = (sg_to ** 2 * (sg ** 2 - sg_to ** 2) / sg ** 2) ** 0.5
+                down = (sg_to ** 2 - up ** 2) ** 0.5
+                assert abs(up ** 2 + down ** 2 - sg_to ** 2) <= 1e-9 * max(sg_to ** 2, 1e-30)
+                want = x0.double() + (down / sg) * (x.double() - x0.double()) + up * nz.double()
+                torch.testing.assert_close(s.step(p, v.float(), t, x, noise=torch.zeros(5, 7)),
+                                           s.step(p, v.float(), t, x, noise=nz) - nz * s.step_coeffs(t)[4], rtol=1e-5, atol=1e-5 * max(sg, 1.0))
+            torch.testing.assert_close(got.double(), want, rtol=2e-5, atol=2e-4 * max(sg, 1.0) * 1e-2)
+            if i == 49:
+                torch.testing.assert_close(got, x0, rtol=1e-5, atol=1e-5)
+
+
+def test_dpmpp_known_answers():
+    """DPM-Solver++: the first-order update IS the DDIM step in the alpha / sigma parametrisation (x_next = alpha_next x0 + sig_next eps
+    with x0, eps from the v-prediction), checked against an independent float64 DDIM evaluation; the second-order (2M, midpoint)
+    update against its closed form x_next = A x - B (x0_i + (x0_i - x0_{i-1}) / (2 r0)); order 1 on the first and on the last step."""
+    import math
+    g = torch.Generator().manual_seed(2)
+    p = Prec("fp32")
+    s = dr.DPMSolverMultistepScheduler()
+    s.set_timesteps(50)
+    al = lambda sg: 1 / math.sqrt(sg ** 2 + 1)
+    x, v = torch.randn(4, 6, generator=g), torch.randn(4, 6, generator=g)
+    # step 0: first order
+    sg0, sg1, sg2 = (float(s.sigmas[i]) for i in (0, 1, 2))
+    a0, a1, a2 = al(sg0), al(sg1), al(sg2)
+    b0, b1, b2 = sg0 * a0, sg1 * a1, sg2 * a2
+    assert s.step_coeffs(999)[4] is None
+    got = s.step(p, v, 999, x)
+    x0_0 = a0 * x.double() - b0 * v.double()
+    eps_0 = a0 * v.double() + b0 * x.double()
+    torch.testing.assert_close(got.double(), a1 * x0_0 + b1 * eps_0, rtol=1e-4, atol=1e-4)          # == DDIM
+    # step 1: second order with the history of step 0
+    assert s.lower_order_nums == 1 and s.step_coeffs(979)[4] is not None
+    v1 = torch.randn(4, 6, generator=g)
+    got2 = s.step(p, v1, 979, got)
+    x0_1 = a1 * got.double() - b1 * v1.double()
+    lam = lambda a, b: math.log(a) - math.log(b)
+    h, h0 = lam(a2, b2) - lam(a1, b1), lam(a1, b1) - lam(a0, b0)
+    A, B = b2 / b1, a2 * (math.exp(-h) - 1.0)
+    want2 = A * got.double() - B * (x0_1 + (x0_1 - x0_0) / (2 * (h0 / h)))
+    torch.testing.assert_close(got2.double(), want2, rtol=1e-4, atol=1e-4)
+    # last step: first order onto x0 (final sigma 0: A = 0, B = -1)
+    s.lower_order_nums = 2
+    c = s.step_coeffs(19)
+    assert c[4] is None and float(c[2]) == 0.0 and float(c[3]) == -1.0

@@ -201,6 +201,42 @@ def test_pipeline_strength_below_one_matches_oracle(setup):
         pipe(**dict(kw, eta=0.5))
 
 
+@pytest.mark.parametrize("name", ["Euler", "Euler A", "DPM++"])
+def test_pipeline_other_samplers_match_oracle(setup, name):
+    """The reference's sampler table beyond DDIM (demo.py:647-657): `TrajCrafter_Pipeline` with the "Euler" / "Euler A" / "DPM++"
+    scheduler, 4 CFG steps from `latents=` (scaled by init_noise_sigma = sigma_max for the Euler pair, :440-446; model input through
+    `scale_model_input`, :1099-1101), against the oracle's loop with the restated diffusers schedulers — bf16 contract and fp32
+    (`_check_deep`).  "Euler A": the per-step noise is drawn from the call's generator on the device; the oracle receives the
+    same draws.  Restated schedulers: parity unpinned (diffusers absent), KATs in tests/test_oracle_kat.py."""
+    from oracle import diffusers_restated as dr
+    from trajectorycrafter_amd import scheduler as S
+    from trajectorycrafter_amd.models.pipeline_trajectorycrafter import TrajCrafter_Pipeline
+    s, tp = setup, setup["tp"]
+    dev = s["dev"]
+    pc, oc = {"Euler": (S.EulerDiscreteScheduler, dr.EulerDiscreteScheduler), "Euler A": (S.EulerAncestralDiscreteScheduler,
+              dr.EulerAncestralDiscreteScheduler), "DPM++": (S.DPMSolverMultistepScheduler, dr.DPMSolverMultistepScheduler)}[name]
+    pipe = TrajCrafter_Pipeline(None, None, s["pipe"].vae, s["pipe"].transformer, pc())
+    kw = dict(prompt=None, height=32, width=48, num_frames=9, num_inference_steps=4, guidance_scale=6.0,
+              prompt_embeds=tp["prompt_embeds"].to(BF), negative_prompt_embeds=tp["negative_prompt_embeds"].to(BF),
+              latents=tp["latents0"].to(BF), inpaint_latents=s["inpaint"].to(BF), ref_latents=s["ref"].to(BF))
+    lat = pipe(output_type="latent", generator=torch.Generator(device=dev).manual_seed(21), **kw).videos
+    assert lat.dtype == BF and torch.isfinite(lat.float()).all()
+    gref = torch.Generator(device=dev).manual_seed(21)
+    draws = [torch.randn(tp["latents0"].shape, generator=gref, device=dev, dtype=torch.float32).cpu() for _ in range(4)] if name == "Euler A" else None
+    args = (s["wt"], s["tr_cfg"], tp["latents0"].to(BF).float(), tp["prompt_embeds"].to(BF).float(), tp["negative_prompt_embeds"].to(BF).float(),
+            s["inpaint"].to(BF).float(), s["ref"].to(BF).float(), 32, 48, 4, 6.0)
+    noise_fn = (lambda i, shape: draws[i]) if draws is not None else None
+    con = opl.denoise(*args, prec="bf16", scheduler=oc(), step_noise=noise_fn)
+    ex = opl.denoise(*args, prec="fp32", scheduler=oc(), step_noise=noise_fn)
+    _check_deep(lat, con, ex, f"pipeline latents after 4 CFG steps, sampler {name}")
+    # a different sampler gives a different clip; the same call twice the same clip
+    ddim = s["pipe"](output_type="latent", **kw).videos
+    assert not torch.equal(lat, ddim)
+    assert torch.equal(pipe(output_type="latent", generator=torch.Generator(device=dev).manual_seed(21), **kw).videos, lat)
+    with pytest.raises(NotImplementedError, match="add_noise"):
+        pipe(**dict({k: v for k, v in kw.items() if k != "latents"}, strength=0.5, video=tp["video"]))
+
+
 def test_conditioning_from_pixels_matches_oracle(setup):
     """reference :862-897, :927-1028 through the HIP VAE encoder: masked-video latents + resized mask (deterministic:
     `.mode()`), and the reference-frame posterior (mean / std; its `.sample()` draws from the device RNG)."""

@@ -213,6 +213,48 @@ __global__ __launch_bounds__(256) void cfg_ddim_cog_kernel(const void* u, const 
     }
 }
 
+// Sigma-parametrised samplers (diffusers EulerDiscrete / EulerAncestralDiscrete / DPMSolverMultistep++ 2M), v-prediction.
+// The coefficients are the library's own 0-dim fp32 scalars, computed on the host; every per-element operation below is the
+// fp32 operation the library's tensor expression performs, in its order (no contraction: -ffp-contract=off).
+//   KIND 0 (Euler):  x0 = v a + x / s2p1;  d = (x - x0) / sigma;  prev = x + d dt  [+ noise sigma_up]
+//   KIND 1 (DPM++):  x0 = bf16r(alpha x) - sig v (kept in `hist_out`);  prev = A x - B x0  [- (B/2) (inv_r0 (x0 - x0_prev))]
+template <bool PRED_F32, int KIND>
+__global__ __launch_bounds__(256) void cfg_sigma_step_kernel(const void* u, const void* c, const uint16_t* x, uint16_t* out,
+                                                             int64_t n, float g, float k0, float k1, float k2, float k3, float k4,
+                                                             const float* hist_in, float* hist_out, const float* noise) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float uu, cc = 0.f;
+        if constexpr (PRED_F32) {
+            uu = reinterpret_cast<const float*>(u)[i];
+            if (c) cc = reinterpret_cast<const float*>(c)[i];
+        } else {
+            uu = bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(u)[i]);
+            if (c) cc = bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(c)[i]);
+        }
+        const float v = c ? uu + g * (cc - uu) : uu;
+        const float xs = bf16_bits_to_f32(x[i]);
+        float prev;
+        if constexpr (KIND == 0) {
+            const float x0 = v * k0 + xs / k1;
+            const float d = (xs - x0) / k2;
+            prev = xs + d * k3;
+            if (noise) prev = prev + noise[i] * k4;
+        } else {
+            const float x0 = round_bf16(k0 * xs) - k1 * v;
+            hist_out[i] = x0;
+            prev = k2 * xs - k3 * x0;
+            if (hist_in) prev = prev - (0.5f * k3) * (k4 * (x0 - hist_in[i]));
+        }
+        out[i] = (uint16_t)(pack_bf16(prev, 0.f) & 0xffff);
+    }
+}
+
+// y = bf16(x / d): `scale_model_input` of the Euler samplers (a bf16 tensor divided by a 0-dim fp32 tensor stays bf16)
+__global__ __launch_bounds__(256) void div_kernel(const uint16_t* x, uint16_t* y, int64_t n, float d) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = (uint16_t)(pack_bf16(bf16_bits_to_f32(x[i]) / d, 0.f) & 0xffff);
+}
+
 // [N, C, S] (S = T*H*W) bf16 -> channels-last [N, S, C] bf16, scaled by `mul`; LDS-tiled transpose
 __global__ __launch_bounds__(256) void ncthw_to_cl_kernel(const uint16_t* x, uint16_t* y, int32_t C, int64_t S, float mul) {
     __shared__ uint16_t tile[32][33];
@@ -430,6 +472,43 @@ extern "C" int tcx_cfg_ddim_cog_step(const void* u, const void* c, const void* x
         hipLaunchKernelGGL(cfg_ddim_cog_kernel<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, sqrt_alpha_t, sqrt_beta_t, coef_sample, coef_x0);
     else
         hipLaunchKernelGGL(cfg_ddim_cog_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, sqrt_alpha_t, sqrt_beta_t, coef_sample, coef_x0);
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_cfg_sigma_step(const void* u, const void* c, const void* x, void* out, int64_t n, float guidance, int32_t kind,
+                                  const float* coef, const float* hist_in, float* hist_out, const float* noise, int32_t pred_dtype,
+                                  void* stream) {
+    TCX_CHECK(u && x && out && coef, TCX_E_NULL, "tcx_cfg_sigma_step: null pointer");
+    TCX_CHECK(n > 0, TCX_E_SHAPE, "tcx_cfg_sigma_step: n must be positive");
+    TCX_CHECK(pred_dtype == TCX_BF16 || pred_dtype == TCX_F32, TCX_E_DTYPE, "tcx_cfg_sigma_step: bad pred_dtype %d", pred_dtype);
+    TCX_CHECK(kind == TCX_STEP_EULER || kind == TCX_STEP_DPMPP_2M, TCX_E_SHAPE, "tcx_cfg_sigma_step: unknown kind %d", kind);
+    const float k0 = coef[0], k1 = coef[1], k2 = coef[2], k3 = coef[3], k4 = coef[4];
+    for (int j = 0; j < 5; ++j) TCX_CHECK(coef[j] == coef[j], TCX_E_SHAPE, "tcx_cfg_sigma_step: coef[%d] is NaN", j);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(grid_for(n));
+    if (kind == TCX_STEP_EULER) {
+        TCX_CHECK(k1 > 0.f && k2 > 0.f, TCX_E_SHAPE, "tcx_cfg_sigma_step: Euler needs sigma^2 + 1 > 0 and sigma > 0 (coef[1], coef[2])");
+        TCX_CHECK(!hist_in && !hist_out, TCX_E_SHAPE, "tcx_cfg_sigma_step: the Euler step keeps no history");
+        if (pred_dtype == TCX_F32)
+            hipLaunchKernelGGL((cfg_sigma_step_kernel<true, 0>), grid, dim3(256), 0, st, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, k0, k1, k2, k3, k4, nullptr, nullptr, noise);
+        else
+            hipLaunchKernelGGL((cfg_sigma_step_kernel<false, 0>), grid, dim3(256), 0, st, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, k0, k1, k2, k3, k4, nullptr, nullptr, noise);
+    } else {
+        TCX_CHECK(hist_out != nullptr, TCX_E_NULL, "tcx_cfg_sigma_step: DPM++ needs hist_out (the x0 prediction kept for the next step)");
+        TCX_CHECK(!noise, TCX_E_SHAPE, "tcx_cfg_sigma_step: DPM-Solver++ (deterministic) takes no noise");
+        TCX_CHECK(hist_in != hist_out, TCX_E_SHAPE, "tcx_cfg_sigma_step: hist_in and hist_out must be different buffers");
+        if (pred_dtype == TCX_F32)
+            hipLaunchKernelGGL((cfg_sigma_step_kernel<true, 1>), grid, dim3(256), 0, st, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, k0, k1, k2, k3, k4, hist_in, hist_out, nullptr);
+        else
+            hipLaunchKernelGGL((cfg_sigma_step_kernel<false, 1>), grid, dim3(256), 0, st, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, k0, k1, k2, k3, k4, hist_in, hist_out, nullptr);
+    }
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_div_bf16(const void* x, void* y, int64_t n, float d, void* stream) {
+    TCX_CHECK(x && y, TCX_E_NULL, "tcx_div_bf16: null pointer");
+    TCX_CHECK(n > 0 && d != 0.f && d == d, TCX_E_SHAPE, "tcx_div_bf16: n must be positive and the divisor a non-zero number");
+    hipLaunchKernelGGL(div_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, n, d);
     TCX_LAUNCH_RET();
 }
 

@@ -110,6 +110,7 @@ class DenoiseState:
     do_cfg: bool
     guidance_scale: float
     use_dynamic_cfg: bool = False
+    generator: Optional[torch.Generator] = None   # the call's generator: "Euler A" draws its per-step noise from it (:1073, :1166)
 
 
 class TrajCrafter_Pipeline:
@@ -126,7 +127,8 @@ class TrajCrafter_Pipeline:
         if not hasattr(self.scheduler, "fused_cfg_step"):
             raise NotImplementedError(
                 f"scheduler {type(self.scheduler).__name__} is not built on this path: the denoise loop fuses CFG + step into one "
-                "kernel per scheduler class; built: scheduler.DDIMScheduler ('DDIM_Origin'), scheduler.CogVideoXDDIMScheduler ('DDIM_Cog')")
+                "kernel per scheduler class; built (trajectorycrafter_amd.scheduler): DDIMScheduler ('DDIM_Origin'), CogVideoXDDIMScheduler "
+                "('DDIM_Cog'), EulerDiscreteScheduler ('Euler'), EulerAncestralDiscreteScheduler ('Euler A'), DPMSolverMultistepScheduler ('DPM++')")
         self.vae_scale_factor_spatial = 2 ** (len(self.vae.config.block_out_channels) - 1) if vae is not None else 8
         self.vae_scale_factor_temporal = int(self.vae.config.temporal_compression_ratio) if vae is not None else 4
         self.vae_scale_factor = self.vae_scale_factor_spatial
@@ -515,14 +517,15 @@ class TrajCrafter_Pipeline:
                             ref_input=ref_input.contiguous(), image_rotary_emb=image_rotary_emb,
                             timesteps=[int(t) for t in timesteps.tolist()], num_inference_steps=num_inference_steps,
                             batch_size=batch_size, do_cfg=do_cfg, guidance_scale=float(guidance_scale),
-                            use_dynamic_cfg=use_dynamic_cfg)
+                            use_dynamic_cfg=use_dynamic_cfg, generator=generator if not isinstance(generator, list) else generator[0])
 
     @torch.no_grad()
     def denoise_step(self, st: "DenoiseState", t: int) -> torch.Tensor:
         """One iteration of the reference loop (:1093-1178): CFG-batched transformer forward, guidance, DDIM update,
         bf16 latents.  Updates and returns `st.latents`.  No host synchronisation."""
         device = st.latents.device
-        latent_model_input = torch.cat([st.latents] * 2) if st.do_cfg else st.latents
+        lat_in = self.scheduler.scale_model_input(st.latents, t)                   # :1099-1101 (identity for the DDIM samplers)
+        latent_model_input = torch.cat([lat_in] * 2) if st.do_cfg else lat_in
         timestep = torch.full((latent_model_input.shape[0],), t, device=device, dtype=torch.int64)
         noise_pred = self.transformer(hidden_states=latent_model_input, encoder_hidden_states=st.prompt_embeds,
                                       timestep=timestep, image_rotary_emb=st.image_rotary_emb, return_dict=False,
@@ -532,9 +535,9 @@ class TrajCrafter_Pipeline:
             self._guidance_scale = 1 + st.guidance_scale * ((1 - math.cos(math.pi * ((n - t) / n) ** 5.0)) / 2)
         if st.do_cfg:                                                              # :1157-1178 fused, per scheduler class
             u, c = noise_pred[:st.batch_size], noise_pred[st.batch_size:]
-            st.latents = self.scheduler.fused_cfg_step(u, c, st.latents, self.guidance_scale, t)
+            st.latents = self.scheduler.fused_cfg_step(u, c, st.latents, self.guidance_scale, t, generator=st.generator)
         else:
-            st.latents = self.scheduler.fused_cfg_step(noise_pred, None, st.latents, 1.0, t)
+            st.latents = self.scheduler.fused_cfg_step(noise_pred, None, st.latents, 1.0, t, generator=st.generator)
         return st.latents
 
     def timings(self) -> Dict[str, float]:

@@ -287,6 +287,45 @@ def cfg_ddim_cog_step(uncond: torch.Tensor, cond: Optional[torch.Tensor], x: tor
     return out
 
 
+def cfg_sigma_step(kind: int, uncond: torch.Tensor, cond: Optional[torch.Tensor], x: torch.Tensor, guidance: float, coef,
+                   hist_in: Optional[torch.Tensor] = None, hist_out: Optional[torch.Tensor] = None,
+                   noise: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """CFG + the `step` of a sigma-parametrised sampler, fused (`tcx_cfg_sigma_step`): kind `_lib.TCX_STEP_EULER` ("Euler", and
+    "Euler A" with `noise`) or `_lib.TCX_STEP_DPMPP_2M` ("DPM++": `hist_out` receives this step's x0, `hist_in` is the previous
+    one).  `coef`: the 5 fp32 scalars of include/tcx_hip.h, from the scheduler."""
+    import ctypes
+    _need(x, "x")
+    if uncond.dtype not in (BF16, torch.float32):
+        raise TcxError(f"cfg_sigma_step: prediction dtype {uncond.dtype} unsupported")
+    if not (uncond.is_contiguous() and x.is_contiguous() and (cond is None or cond.is_contiguous())):
+        raise TcxError("cfg_sigma_step: tensors must be contiguous")
+    if uncond.numel() != x.numel() or (cond is not None and (cond.numel() != x.numel() or cond.dtype != uncond.dtype)):
+        raise TcxError("cfg_sigma_step: size / dtype mismatch")
+    for name, t in (("hist_in", hist_in), ("hist_out", hist_out), ("noise", noise)):
+        if t is not None:
+            _need(t, name, torch.float32)
+            if not t.is_contiguous() or t.numel() != x.numel():
+                raise TcxError(f"cfg_sigma_step: {name} must be a contiguous fp32 tensor of the latents' size")
+    if len(coef) != 5:
+        raise TcxError("cfg_sigma_step: coef holds 5 scalars")
+    carr = (ctypes.c_float * 5)(*[float(v) for v in coef])
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.load().tcx_cfg_sigma_step(_p(uncond), _p(cond), _p(x), _p(out), x.numel(), float(guidance), int(kind),
+                                         ctypes.cast(carr, ctypes.c_void_p), _p(hist_in), _p(hist_out), _p(noise),
+                                         TCX_F32 if uncond.dtype == torch.float32 else TCX_BF16, _stream()), "tcx_cfg_sigma_step")
+    return out
+
+
+def div_bf16(x: torch.Tensor, d: float) -> torch.Tensor:
+    """bf16(x / d) (`tcx_div_bf16`): the Euler samplers' `scale_model_input`."""
+    _need(x, "x")
+    if not x.is_contiguous():
+        raise TcxError("div_bf16: x must be contiguous")
+    y = torch.empty_like(x)
+    check(_lib.load().tcx_div_bf16(_p(x), _p(y), x.numel(), float(d), _stream()), "tcx_div_bf16")
+    return y
+
+
 # ----------------------------------------------------------------------------- VAE (channels-last [N,T,H,W,C])
 def conv3d_cl(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], cache: Optional[torch.Tensor] = None,
               res: Optional[torch.Tensor] = None, ups: int = 0, t_map: Optional[torch.Tensor] = None,

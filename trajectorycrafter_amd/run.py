@@ -27,19 +27,20 @@ from typing import Optional
 
 import torch
 
-SAMPLERS = ("DDIM_Origin", "DDIM_Cog")                       # built; the reference's table (demo.py:647-654) has four more
-_NOT_BUILT = ("Euler", "Euler A", "DPM++", "PNDM")
+SAMPLERS = ("DDIM_Origin", "DDIM_Cog", "Euler", "Euler A", "DPM++")      # built; the reference's table (demo.py:647-654) has one more
+_NOT_BUILT = ("PNDM",)
 
 
 def make_scheduler(sampler_name: str, model_dir: Optional[str]):
     """demo.py:647-657: the sampler table + `from_pretrained(model_name, subfolder="scheduler")`; the class defaults (the
     CogVideoX-Fun-V1.1-5b-InP values as recalled, scheduler.py) when the directory holds no scheduler_config.json."""
-    from .scheduler import CogVideoXDDIMScheduler, DDIMScheduler
+    from . import scheduler as S
     if sampler_name in _NOT_BUILT:
         raise NotImplementedError(f"sampler {sampler_name!r} is in the reference's table but not built on this path; built: {SAMPLERS}")
     if sampler_name not in SAMPLERS:
         raise ValueError(f"unknown sampler {sampler_name!r}; the reference's choices: {SAMPLERS + _NOT_BUILT}")
-    cls = {"DDIM_Origin": DDIMScheduler, "DDIM_Cog": CogVideoXDDIMScheduler}[sampler_name]
+    cls = {"DDIM_Origin": S.DDIMScheduler, "DDIM_Cog": S.CogVideoXDDIMScheduler, "Euler": S.EulerDiscreteScheduler,
+           "Euler A": S.EulerAncestralDiscreteScheduler, "DPM++": S.DPMSolverMultistepScheduler}[sampler_name]
     if model_dir and os.path.exists(os.path.join(model_dir, "scheduler", "scheduler_config.json")):
         return cls.from_pretrained(model_dir, subfolder="scheduler")
     return cls()

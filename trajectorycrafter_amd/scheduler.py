@@ -96,7 +96,7 @@ class DDIMScheduler:
         return sa * original_samples + sb * noise
 
     def fused_cfg_step(self, uncond: torch.Tensor, cond: Optional[torch.Tensor], sample: torch.Tensor, guidance: float,
-                       timestep: int) -> torch.Tensor:
+                       timestep: int, generator=None) -> torch.Tensor:
         """CFG combine (pipeline :1157-1161) + `step` + the bf16 cast (:1178) as ONE kernel (`tcx_cfg_ddim_step`)."""
         from . import ops
         a_t, a_prev = self.coeffs(int(timestep))
@@ -143,7 +143,172 @@ class CogVideoXDDIMScheduler(DDIMScheduler):
         ca = ((1 - a_prev) / (1 - a_t)) ** 0.5
         return a_t ** 0.5, (1 - a_t) ** 0.5, ca, a_prev ** 0.5 - a_t ** 0.5 * ca
 
-    def fused_cfg_step(self, uncond, cond, sample, guidance: float, timestep: int) -> torch.Tensor:
+    def fused_cfg_step(self, uncond, cond, sample, guidance: float, timestep: int, generator=None) -> torch.Tensor:
         from . import ops
         sa, sb, ca, cb = self.step_coeffs(timestep)
         return ops.cfg_ddim_cog_step(uncond, cond, sample, guidance, sa, sb, ca, cb)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The sigma-parametrised samplers of the reference's table (demo.py:647-654): "Euler", "Euler A", "DPM++".
+# diffusers EulerDiscreteScheduler / EulerAncestralDiscreteScheduler / DPMSolverMultistepScheduler as `from_pretrained` builds
+# them from the CogVideoX scheduler_config.json (scaled_linear betas, v_prediction, trailing spacing, zero-terminal-SNR rescale —
+# these classes then pin alphas_cumprod[-1] to 2^-24, i.e. sigma_max = 4096; unknown keys such as snr_shift_scale are ignored by the
+# library and here).  Restated from the published algorithms (diffusers is absent offline: parity unpinned, like the DDIM classes).
+# Host side: fp32 tables and, per step, the library's 0-dim fp32 coefficient expressions evaluated with torch in the library's
+# order; device side: ONE fused kernel per step (`tcx_cfg_sigma_step`: guidance + step + bf16 cast) and, for the Euler pair,
+# `tcx_div_bf16` for `scale_model_input`.
+# ---------------------------------------------------------------------------------------------------------------------------
+class _SigmaSampler:
+    order = 1
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
+                 beta_schedule: str = "scaled_linear", prediction_type: str = "v_prediction", timestep_spacing: str = "trailing",
+                 rescale_betas_zero_snr: bool = True, steps_offset: int = 0, **unused):
+        if beta_schedule != "scaled_linear":
+            raise ValueError(f"beta_schedule {beta_schedule!r} not supported")
+        if prediction_type != "v_prediction":
+            raise ValueError("the fused HIP step implements v_prediction (CogVideoX); got " + prediction_type)
+        if timestep_spacing not in ("trailing", "leading"):
+            raise ValueError(f"timestep_spacing {timestep_spacing!r} not supported")
+        self.config = FrozenConfig(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                   beta_schedule=beta_schedule, prediction_type=prediction_type, timestep_spacing=timestep_spacing,
+                                   rescale_betas_zero_snr=rescale_betas_zero_snr, steps_offset=steps_offset)
+        base = DDIMScheduler(num_train_timesteps, beta_start, beta_end, beta_schedule, prediction_type, "trailing",
+                             rescale_betas_zero_snr)                       # the same fp32 beta / zero-SNR arithmetic
+        self.betas = base.betas
+        self.alphas_cumprod = base.alphas_cumprod.clone()
+        if rescale_betas_zero_snr:
+            self.alphas_cumprod[-1] = 2 ** -24                              # finite first sigma (4096) instead of inf
+        self._train_sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        self.sigmas: Optional[torch.Tensor] = None
+        self.timesteps: Optional[torch.Tensor] = None
+        self.num_inference_steps: Optional[int] = None
+
+    from_pretrained = classmethod(DDIMScheduler.from_pretrained.__func__)
+
+    def _spaced(self, n: int) -> np.ndarray:
+        N = self.config.num_train_timesteps
+        if n > N:
+            raise ValueError(f"num_inference_steps ({n}) > num_train_timesteps ({N})")
+        if self.config.timestep_spacing == "trailing":
+            return np.round(np.arange(N, 0, -N / n)) - 1
+        return (np.arange(0, n) * (N // n)).round()[::-1].copy().astype(np.float64) + self.config.steps_offset
+
+    def _set_tables(self, n: int, ts_dtype) -> None:
+        ts = self._spaced(n).astype(ts_dtype)
+        sig = np.interp(ts, np.arange(0, len(self._train_sigmas)), self._train_sigmas)       # interpolation_type "linear"
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))     # final_sigmas_type "zero"
+        self.timesteps = torch.from_numpy(ts)
+        self.num_inference_steps = n
+        self._index = {int(t): i for i, t in enumerate(ts.tolist())}
+        if len(self._index) != len(ts):
+            raise ValueError("duplicate timesteps in the schedule (more inference steps than distinct train steps) are not supported")
+
+    def _i(self, timestep) -> int:
+        if self.sigmas is None:
+            raise RuntimeError("call set_timesteps first")
+        try:
+            return self._index[int(timestep)]
+        except KeyError:
+            raise ValueError(f"timestep {timestep} is not on the schedule set by set_timesteps({self.num_inference_steps})") from None
+
+    def scale_model_input(self, sample: torch.Tensor, timestep=None) -> torch.Tensor:
+        return sample
+
+    def add_noise(self, original_samples, noise, timesteps):
+        raise NotImplementedError(f"{type(self).__name__}.add_noise (the `strength < 1` start of pipeline :431-436) is built for the "
+                                  "DDIM samplers only ('DDIM_Origin', 'DDIM_Cog')")
+
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, generator=None, return_dict: bool = False, **kw):
+        """diffusers-shaped step (no guidance) on the fused kernel."""
+        return (self.fused_cfg_step(model_output.contiguous(), None, sample.contiguous(), 1.0, timestep, generator=generator),)
+
+
+class EulerDiscreteScheduler(_SigmaSampler):
+    """ "Euler": x_in = x / sqrt(sigma^2 + 1);  x0 = v (-sigma / sqrt(sigma^2 + 1)) + x / (sigma^2 + 1);  d = (x - x0) / sigma;
+    x_next = x + d (sigma_next - sigma), fp32, then the loop's bf16 cast.  s_churn = 0 (the pipeline passes none)."""
+    ancestral = False
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self._set_tables(num_inference_steps, np.float32)                   # timestep_type "discrete": float32 timesteps
+
+    @property
+    def init_noise_sigma(self) -> float:
+        mx = float(self.sigmas.max()) if self.sigmas is not None else float(self._train_sigmas.max())
+        return mx if self.config.timestep_spacing == "trailing" else float((torch.tensor(mx) ** 2 + 1) ** 0.5)
+
+    def scale_model_input(self, sample: torch.Tensor, timestep=None) -> torch.Tensor:
+        from . import ops
+        sigma = self.sigmas[self._i(timestep)]
+        return ops.div_bf16(sample.contiguous(), float((sigma ** 2 + 1) ** 0.5))
+
+    def step_coeffs(self, timestep):
+        i = self._i(timestep)
+        sigma, sigma_to = self.sigmas[i], self.sigmas[i + 1]
+        a, s2p1 = -sigma / (sigma ** 2 + 1) ** 0.5, sigma ** 2 + 1
+        if not self.ancestral:
+            return [float(a), float(s2p1), float(sigma), float(sigma_to - sigma), 0.0]
+        sigma_up = (sigma_to ** 2 * (sigma ** 2 - sigma_to ** 2) / sigma ** 2) ** 0.5
+        sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+        return [float(a), float(s2p1), float(sigma), float(sigma_down - sigma), float(sigma_up)]
+
+    def fused_cfg_step(self, uncond, cond, sample, guidance: float, timestep, generator=None) -> torch.Tensor:
+        from . import _lib, ops
+        noise = None
+        if self.ancestral:      # randn_tensor(model_output.shape, dtype=model_output.dtype (fp32 in the loop), generator=generator)
+            gdev = generator.device if generator is not None else sample.device
+            noise = torch.randn(sample.shape, generator=generator, device=gdev, dtype=torch.float32).to(sample.device)
+        return ops.cfg_sigma_step(_lib.TCX_STEP_EULER, uncond, cond, sample, guidance, self.step_coeffs(timestep), noise=noise)
+
+
+class EulerAncestralDiscreteScheduler(EulerDiscreteScheduler):
+    """ "Euler A": the Euler step to sigma_down, then + N(0, 1) sigma_up (one fp32 draw of the latents' shape per step from the
+    call's generator), with sigma_up^2 = sigma_next^2 (sigma^2 - sigma_next^2) / sigma^2 and sigma_down^2 = sigma_next^2 - sigma_up^2."""
+    ancestral = True
+
+
+class DPMSolverMultistepScheduler(_SigmaSampler):
+    """ "DPM++": DPM-Solver++ 2M (midpoint), first-order on the first step and on the last (final sigma 0); keeps the previous
+    step's data prediction x0 (fp32, the latents' size) between steps.  init_noise_sigma = 1, int64 timesteps."""
+    init_noise_sigma = 1.0
+    solver_order = 2
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self._set_tables(num_inference_steps, np.int64)
+        self._hist = [None, None]                                           # [previous x0, scratch for this step's]
+        self._lower_order_nums = 0
+
+    @staticmethod
+    def _alpha_sig(sigma: torch.Tensor):
+        alpha = 1 / ((sigma ** 2 + 1) ** 0.5)
+        return alpha, sigma * alpha
+
+    def step_coeffs(self, timestep):
+        """([alpha_i, sig_i, A, B, 1/r0], second_order) — the library's expressions on 0-dim fp32 tensors."""
+        i, n = self._i(timestep), len(self.timesteps)
+        alpha_t, sig_t = self._alpha_sig(self.sigmas[i + 1])
+        alpha_s, sig_s = self._alpha_sig(self.sigmas[i])
+        lam_t, lam_s = torch.log(alpha_t) - torch.log(sig_t), torch.log(alpha_s) - torch.log(sig_s)
+        h = lam_t - lam_s
+        A, B = sig_t / sig_s, alpha_t * (torch.exp(-h) - 1.0)
+        if self._lower_order_nums < 1 or i == n - 1:                        # warm-up step / lower_order_final (final sigma 0)
+            return [float(alpha_s), float(sig_s), float(A), float(B), 0.0], False
+        alpha_p, sig_p = self._alpha_sig(self.sigmas[i - 1])
+        r0 = (lam_s - (torch.log(alpha_p) - torch.log(sig_p))) / h
+        return [float(alpha_s), float(sig_s), float(A), float(B), float(1.0 / r0)], True
+
+    def fused_cfg_step(self, uncond, cond, sample, guidance: float, timestep, generator=None) -> torch.Tensor:
+        from . import _lib, ops
+        coef, second = self.step_coeffs(timestep)
+        prev_x0, scratch = self._hist
+        if second and (prev_x0 is None or prev_x0.shape != sample.shape or prev_x0.device != sample.device):
+            raise RuntimeError("DPM++: the previous step's data prediction is missing (steps must run in schedule order after set_timesteps)")
+        if scratch is None or scratch.shape != sample.shape or scratch.device != sample.device:
+            scratch = torch.empty(sample.shape, device=sample.device, dtype=torch.float32)
+        out = ops.cfg_sigma_step(_lib.TCX_STEP_DPMPP_2M, uncond, cond, sample, guidance, coef,
+                                 hist_in=prev_x0 if second else None, hist_out=scratch)
+        self._hist = [scratch, prev_x0]                                     # ping-pong: this step's x0 becomes "previous"
+        if self._lower_order_nums < self.solver_order:
+            self._lower_order_nums += 1
+        return out
