@@ -284,27 +284,41 @@ def run_rank(args):
     import torch.distributed as dist
     from trajectorycrafter_amd import dp, ops
 
-    # RCCL ("nccl") is THE collective backend of the path.  gloo (host-mediated) is used when asked for explicitly
-    # (TCX_DIST_BACKEND=gloo: the one-card rehearsal) or, LOUDLY, when RCCL's communicator cannot be created (eager init: `device_id`
-    # is passed, so the failure surfaces here and on every rank): the error goes to stderr and into the JSON line's top level
-    # (`collective_fallback`), so a host-staged gather can never pass for an RCCL scaling number.  TCX_BENCH_RCCL_FATAL=1 turns the
-    # fallback into exit code 3.
+    # Two groups.  Control plane (barriers, the max-over-ranks of the timings, the agreement below): a gloo group, always.  Data
+    # plane = THE collective of the path, the one all-gather per clip: an RCCL ("nccl") group over xGMI.  Each rank probes it with a
+    # one-element all-reduce and the MIN of the outcomes over the gloo group decides for ALL ranks together — a failure on some
+    # ranks only can therefore not leave the others waiting inside an RCCL call.  If RCCL cannot run, the gather goes over gloo
+    # (host-mediated) LOUDLY: error text on stderr and in the JSON line's top level (`collective_fallback`), so a host-staged gather
+    # can never pass for an RCCL scaling number; TCX_BENCH_RCCL_FATAL=1 makes it exit code 3 instead.  TCX_DIST_BACKEND=gloo asks
+    # for gloo outright (the one-card rehearsal).
     backend = os.environ.get("TCX_DIST_BACKEND", "nccl")
-    rccl_error = None
+    rccl_error, gather_group = None, None
     if world > 1:
         try:
-            dp.init_distributed(backend)
+            dp.init_distributed("gloo")
         except Exception as e:
-            rccl_error = f"{type(e).__name__}: {e}"
-            print(f"[bench] rank {rank}: init_process_group(backend={backend!r}) FAILED: {rccl_error}", file=sys.stderr, flush=True)
-            if backend != "nccl" or os.environ.get("TCX_BENCH_RCCL_FATAL") == "1":
-                raise SystemExit(3)
-            print(f"[bench] rank {rank}: FALLING BACK to gloo (host-mediated all-gather) — flagged in the JSON line as `collective_fallback`; "
-                  "this is NOT an RCCL measurement", file=sys.stderr, flush=True)
-            if dist.is_initialized():
-                dist.destroy_process_group()
-            backend = "gloo"
-            dp.init_distributed(backend)
+            print(f"[bench] rank {rank}: init_process_group('gloo') FAILED: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            raise SystemExit(3)
+        if backend == "nccl":
+            try:
+                gather_group = dist.new_group(backend="nccl")
+                one = torch.ones(1, device=device)
+                dist.all_reduce(one, group=gather_group)
+                torch.cuda.synchronize()
+                if float(one.item()) != world:
+                    raise RuntimeError(f"RCCL probe all-reduce returned {float(one.item())}, expected {world}")
+            except Exception as e:
+                rccl_error = f"{type(e).__name__}: {e}"
+                print(f"[bench] rank {rank}: RCCL probe (new_group + all_reduce) FAILED: {rccl_error}", file=sys.stderr, flush=True)
+            ok = torch.tensor([0 if rccl_error else 1], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)                       # gloo, CPU tensor: the collective decision
+            if int(ok.item()) == 0:
+                rccl_error = rccl_error or "RCCL probe failed on another rank (see its stderr)"
+                if os.environ.get("TCX_BENCH_RCCL_FATAL") == "1":
+                    raise SystemExit(3)
+                print(f"[bench] rank {rank}: ALL RANKS FALL BACK to gloo (host-mediated all-gather) — flagged in the JSON line as "
+                      "`collective_fallback`; this is NOT an RCCL measurement", file=sys.stderr, flush=True)
+                backend, gather_group = "gloo", None
         if backend != "nccl":
             print(f"[bench] WARNING: collective backend is {backend!r}, not RCCL: the all-gather is host-mediated; this is a rehearsal, "
                   "not a scaling measurement", file=sys.stderr, flush=True)
@@ -331,7 +345,7 @@ def run_rank(args):
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            t = torch.tensor([dt], dtype=torch.float64)                    # control plane: gloo, host tensor
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, out
@@ -365,7 +379,7 @@ def run_rank(args):
             dec = lambda: pipe.vae.decode_cl_bf16(lat.permute(0, 2, 1, 3, 4), scale=1.0 / pipe.vae.config.scaling_factor)
             dec()
             decode_s, out_cl = timed(dec)
-            gat = lambda: pipe.vae.cl_to_frames(dp.all_gather_cat(out_cl))
+            gat = lambda: pipe.vae.cl_to_frames(dp.all_gather_cat(out_cl, group=gather_group))
             gat()                                               # warm-up (RCCL channel set-up)
             gather_s, frames = timed(gat)                       # THE collective of the path: once per clip
         assert frames.shape[0] == world and torch.isfinite(frames).all() and 0.0 <= float(frames.min()) and float(frames.max()) <= 1.0
@@ -402,7 +416,7 @@ def run_rank(args):
                        "value_formula": "n_gpus / (denoise_steps * ms_per_step + decode_ms + allgather_ms) * 1000",
                        "frames": args.frames, "height": args.height, "width": args.width, "denoise_steps": args.denoise_steps,
                        "layers": args.layers, "vae_decode": not args.no_decode, "global_batch_clips": world,
-                       "parallelism": f"dp{world}", "collective_backend": (backend if world > 1 else None), "decode_ms": 1e3 * decode_s, "allgather_ms": 1e3 * gather_s,
+                       "parallelism": f"dp{world}", "collective_backend": (backend if world > 1 else None), "control_backend": ("gloo" if world > 1 else None), "decode_ms": 1e3 * decode_s, "allgather_ms": 1e3 * gather_s,
                        "clip_seconds": clip_s, "timed_steps_seconds": elapsed, "init_seconds": t_init,
                        "frames_out": frames_shape,
                        "transformer_mfma_frac": (None if fwd_flop is None else

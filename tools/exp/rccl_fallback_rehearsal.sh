@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 TCX_BENCH_SINGLE_DEVICE=1 timeout -k 10 600 python3 bench.py --gpus 2 --steps 2 --warmup 1 --layers 2 > gpurun_out/r3_rccl_fallback.json 2> gpurun_out/r3_rccl_fallback.err
 echo "rc=$?"
-grep -c "FALLING BACK" gpurun_out/r3_rccl_fallback.err
+grep -c "ALL RANKS FALL BACK" gpurun_out/r3_rccl_fallback.err
 python3 - <<'PY'
 import json
 for line in open("gpurun_out/r3_rccl_fallback.json"):

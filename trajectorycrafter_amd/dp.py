@@ -42,14 +42,14 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
-def all_gather_cat(local: torch.Tensor) -> torch.Tensor:
-    """Single all-gather of equally shaped per-rank tensors -> concatenation in rank order."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def all_gather_cat(local: torch.Tensor, group=None) -> torch.Tensor:
+    """Single all-gather of equally shaped per-rank tensors -> concatenation in rank order (`group`: default group if None)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
-    world = dist.get_world_size()
+    world = dist.get_world_size(group)
     local = local.contiguous()
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local)
+    dist.all_gather_into_tensor(out, local, group=group)
     return out
 
 
