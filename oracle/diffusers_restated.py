@@ -503,6 +503,19 @@ class _SigmaScheduler:
     def scale_model_input(self, p: Prec, sample: torch.Tensor, timestep) -> torch.Tensor:
         return sample
 
+    def add_noise(self, p: Prec, original_samples: torch.Tensor, noise: torch.Tensor, timestep) -> torch.Tensor:
+        """`add_noise` of the sigma samplers (the `strength < 1` start, pipeline :431-436): the sigma table is cast to the SAMPLE dtype
+        and every operation runs in it.  Euler pair: x0 + noise sigma.  DPM++: alpha x0 + sig noise with alpha = 1 / sqrt(sigma^2 + 1),
+        sig = sigma alpha evaluated in that dtype too (each op of the eager bf16 execution rounds)."""
+        dt = p.act_dtype
+        sigma = self.sigmas.to(dt)[self.index_for(timestep)]
+        x0, nz = original_samples.to(dt), noise.to(dt)
+        if isinstance(self, DPMSolverMultistepScheduler):
+            alpha_t = 1 / ((sigma ** 2 + 1) ** 0.5)
+            sigma_t = sigma * alpha_t
+            return (alpha_t * x0 + sigma_t * nz).float()
+        return (x0 + nz * sigma).float()
+
 
 class EulerDiscreteScheduler(_SigmaScheduler):
     """diffusers `EulerDiscreteScheduler` ("Euler"), s_churn = 0:

@@ -390,8 +390,15 @@ def test_sigma_samplers_match_oracle_tables(tmp_path):
                     assert a.step_coeffs(t) == want, (n, t)
         with pytest.raises(ValueError, match="not on the schedule"):
             a.step_coeffs(998)
-        with pytest.raises(NotImplementedError, match="add_noise"):
-            a.add_noise(None, None, None)
+        # add_noise (strength < 1): arithmetic in the sample dtype, bit-equal to the oracle's bf16 / fp32 evaluation
+        g = torch.Generator().manual_seed(4)
+        x0, nz = torch.randn(1, 3, 16, 4, 6, generator=g), torch.randn(1, 3, 16, 4, 6, generator=g)
+        a.set_timesteps(50), b.set_timesteps(50)
+        for t in (999, 499, 19):
+            for dt, mode in ((torch.bfloat16, "bf16"), (torch.float32, "fp32")):
+                got = a.add_noise(x0.to(dt), nz.to(dt), a.timesteps[a._i(t)].reshape(1))
+                want = b.add_noise(Prec(mode), x0.to(dt).float(), nz.to(dt).float(), t)
+                assert got.dtype == dt and torch.equal(got.float(), want), (pc.__name__, t, mode)
     d = tmp_path / "scheduler"
     d.mkdir()
     (d / "scheduler_config.json").write_text(json.dumps({"_class_name": "CogVideoXDDIMScheduler", "_diffusers_version": "0.31.0.dev0",

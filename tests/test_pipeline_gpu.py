@@ -233,8 +233,22 @@ def test_pipeline_other_samplers_match_oracle(setup, name):
     ddim = s["pipe"](output_type="latent", **kw).videos
     assert not torch.equal(lat, ddim)
     assert torch.equal(pipe(output_type="latent", generator=torch.Generator(device=dev).manual_seed(21), **kw).videos, lat)
-    with pytest.raises(NotImplementedError, match="add_noise"):
-        pipe(**dict({k: v for k, v in kw.items() if k != "latents"}, strength=0.5, video=tp["video"]))
+    # strength < 1 with this sampler: the last 2 of 4 steps from the noised video latents (scheduler.add_noise in the latent dtype)
+    skw = dict({k: v for k, v in kw.items() if k != "latents"}, strength=0.5, video=tp["video"])
+    g = lambda: torch.Generator(device=dev).manual_seed(43)
+    torch.manual_seed(9)
+    lat_s = pipe(generator=g(), output_type="latent", **skw).videos
+    torch.manual_seed(9)
+    init_video = pipe._preprocess(tp["video"].to(dev), 32, 48)
+    vl = (pipe.vae.encode(init_video.to(BF))[0].sample() * pipe.vae.config.scaling_factor).to(BF).permute(0, 2, 1, 3, 4)
+    gg = g()
+    noise = torch.randn(vl.shape, generator=gg, device=dev, dtype=BF)
+    draws2 = [torch.randn(vl.shape, generator=gg, device=dev, dtype=torch.float32).cpu() for _ in range(2)] if name == "Euler A" else None
+    nf2 = (lambda i, shape: draws2[i]) if draws2 is not None else None
+    sargs = (s["wt"], s["tr_cfg"], noise.float().cpu()) + args[3:]
+    con_s = opl.denoise(*sargs, prec="bf16", scheduler=oc(), step_noise=nf2, strength=0.5, video_latents=vl.float().cpu())
+    ex_s = opl.denoise(*sargs, prec="fp32", scheduler=oc(), step_noise=nf2, strength=0.5, video_latents=vl.float().cpu())
+    _check_deep(lat_s, con_s, ex_s, f"pipeline latents, strength 0.5, sampler {name}")
 
 
 def test_conditioning_from_pixels_matches_oracle(setup):

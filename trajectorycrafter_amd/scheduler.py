@@ -216,9 +216,20 @@ class _SigmaSampler:
     def scale_model_input(self, sample: torch.Tensor, timestep=None) -> torch.Tensor:
         return sample
 
-    def add_noise(self, original_samples, noise, timesteps):
-        raise NotImplementedError(f"{type(self).__name__}.add_noise (the `strength < 1` start of pipeline :431-436) is built for the "
-                                  "DDIM samplers only ('DDIM_Origin', 'DDIM_Cog')")
+    def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timesteps) -> torch.Tensor:
+        """The library's `add_noise` (the `strength < 1` start, pipeline :431-436): the sigma table cast to the SAMPLE dtype, every
+        operation in it — Euler pair: x0 + noise sigma; DPM++: alpha x0 + sig noise (alpha = 1 / sqrt(sigma^2 + 1), sig = sigma alpha,
+        evaluated in that dtype as well).  Torch elementwise ops on the latent tensor, once per clip."""
+        t = torch.as_tensor(timesteps).reshape(-1).tolist()
+        idx = torch.tensor([self._i(v) for v in t], device=original_samples.device)
+        sigma = self.sigmas.to(device=original_samples.device, dtype=original_samples.dtype)[idx].flatten()
+        while sigma.dim() < original_samples.dim():
+            sigma = sigma.unsqueeze(-1)
+        if isinstance(self, DPMSolverMultistepScheduler):
+            alpha_t = 1 / ((sigma ** 2 + 1) ** 0.5)
+            sigma_t = sigma * alpha_t
+            return alpha_t * original_samples + sigma_t * noise
+        return original_samples + noise * sigma
 
     def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, generator=None, return_dict: bool = False, **kw):
         """diffusers-shaped step (no guidance) on the fused kernel."""
