@@ -78,8 +78,14 @@ def test_generate_entry_point_on_a_checkpoint_dir(golden, tmp_path):
     assert torch.equal(got2, want2.float().cpu())
     assert not torch.equal(got2, got) and float((got2 - got).abs().mean()) < 0.02
 
-    r3 = _run(["generate", "--model-dir", str(ckpt), "--conditioning", cond, "--out", out, "--sampler", "DPM++"])
-    assert r3.returncode != 0 and "not built" in r3.stderr
+    # the other built samplers of the reference's table run through the entry point too (a different clip each)
+    out3 = str(tmp_path / "frames_dpm.safetensors")
+    r3 = _run(["generate", "--model-dir", str(ckpt), "--conditioning", cond, "--out", out3, "--sampler", "DPM++", "--global-seed", "5"])
+    assert r3.returncode == 0, r3.stdout[-1500:] + r3.stderr[-3000:]
+    got3 = load_file(out3)["frames"]
+    assert got3.shape == got.shape and torch.isfinite(got3).all() and not torch.equal(got3, got)
+    r4 = _run(["generate", "--model-dir", str(ckpt), "--conditioning", cond, "--out", out, "--sampler", "PNDM"])
+    assert r4.returncode != 0 and "not built" in r4.stderr
 
 
 def test_orbits_entry_point_single_process(golden, tmp_path):

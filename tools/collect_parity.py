@@ -1,0 +1,18 @@
+"""gpurun_out/r3_parity.jsonl (appended by tests/test_models_gpu.record_parity during `pytest -m gpu` on the GPU box) -> profiles/<tag>_parity.json:
+the last record of every comparison, in first-seen order.   usage: python tools/collect_parity.py [tag]"""
+import json, os, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+recs, order = {}, []
+with open(os.path.join(root, "gpurun_out", "r3_parity.jsonl")) as f:
+    for line in f:
+        if line.strip():
+            r = json.loads(line)
+            if r["test"] not in recs:
+                order.append(r["test"])
+            recs[r["test"]] = r
+out = {"source": "tests -m gpu on MI355X (gpurun), tests/test_models_gpu.record_parity: every _check_deep comparison and the north-star "
+                 "tolerance record of tests/test_pipeline_gpu.py (last run of each)", "records": [recs[t] for t in order]}
+with open(os.path.join(root, "profiles", f"{tag}_parity.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print(len(order), "records ->", f"profiles/{tag}_parity.json")
