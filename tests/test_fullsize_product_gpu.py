@@ -391,6 +391,37 @@ def test_reference_default_resolution_384x672_full_model(gpu):
     _check_deep(got, con, ex, "384x672 2-block CrossTransformer3DModel.forward")
 
 
+@pytest.mark.parametrize("frames,height,width,batch,ref_frames", [(25, 320, 576, 2, 3), (17, 512, 512, 1, 2), (5, 272, 400, 2, 1), (49, 256, 384, 3, 3)])
+def test_two_block_forward_other_resolutions_vs_oracle(gpu, frames, height, width, batch, ref_frames):
+    """Sizes the reference accepts besides its two defaults (any H, W divisible by 16, <= 49 frames): ragged last q-blocks and key
+    tiles in both attentions (S = 5266 / 5346 / 1076 / 5218 + 226 text tokens), ragged GEMM M tiles, odd latent grids (17 x 25
+    patches), batch 1 / 2 / 3, fractional RoPE grids — the full-width 2-block model against the oracle, every element."""
+    from trajectorycrafter_amd import init_weights as iw
+    from trajectorycrafter_amd.models.crosstransformer3d import CrossTransformer3DModel
+    cfg = dict(iw.TRANSFORMER_5B, num_layers=2)
+    sd32 = iw.random_state_dict(iw.transformer_param_shapes(dict(otr.DEFAULT_CONFIG, **cfg)), seed=0, dtype=torch.float32, device=gpu)
+    sd32 = {k: v.to(BF).float() for k, v in sd32.items()}
+    with torch.device("meta"):
+        model = CrossTransformer3DModel(**cfg)
+    model.load_state_dict({k: v.to(BF) for k, v in sd32.items()}, strict=True, assign=True)
+    model.eval()
+    T, h, w = (frames - 1) // 4 + 1, height // 8, width // 8
+    cos, sin = prepare_rotary(height, width, T, 2, 64)
+    rot = (cos.to(gpu), sin.to(gpu))
+    g = torch.Generator(device=gpu).manual_seed(frames + height)
+    rn = lambda *s: torch.randn(*s, device=gpu, dtype=BF, generator=g)
+    hs, txt, inp, cross = rn(batch, T, 16, h, w), rn(batch, 226, 4096), rn(batch, T, 17, h, w), rn(batch, ref_frames, 16, h, w)
+    ts = torch.full((batch,), 759, device=gpu)
+    with torch.no_grad():
+        got = model(hs, txt, ts, inpaint_latents=inp, cross_latents=cross, image_rotary_emb=rot, return_dict=False)[0]
+        con = otr.transformer_forward(sd32, cfg, hs.float(), txt.float(), ts, inp.float(), cross.float(), rot, prec="bf16")
+        ex = otr.transformer_forward(sd32, cfg, hs.float(), txt.float(), ts, inp.float(), cross.float(), rot, prec="fp32")
+    assert got.shape == hs.shape
+    _check_deep(got, con, ex, f"{frames}f {height}x{width} B={batch} 2-block CrossTransformer3DModel.forward")
+    with torch.no_grad():
+        assert torch.equal(model(hs, txt, ts, inpaint_latents=inp, cross_latents=cross, image_rotary_emb=rot, return_dict=False)[0], got)
+
+
 def test_configs2_full_model_two_steps_and_decode(gpu):
     """BASELINE configs[2] smoke at full size: the 42-layer / 6.1 B-parameter model, 2 DDIM steps with CFG + the VAE decode to
     49 frames 480x720 through `TrajCrafter_Pipeline.__call__`: finite, in [0, 1], every frame differs (the decode used all

@@ -410,3 +410,19 @@ def test_sigma_samplers_match_oracle_tables(tmp_path):
         assert type(sch) is pc and type(make_scheduler(name, None)) is pc and sch.config.timestep_spacing == "trailing"
         sch.set_timesteps(50)
         assert int(sch.timesteps[0]) == 999
+
+
+@pytest.mark.parametrize("T", list(range(1, 14)))
+def test_decoded_frame_count_matches_the_chunked_temporal_upsampling(T):
+    """`AutoencoderKLCogVideoX.decoded_frames` (sizes the fused frames epilogue's output) == the frame count of the reference's chunking
+    (:1235-1241) pushed through two temporal nearest upsamplings of diffusers CogVideoXUpsample3D (oracle restatement): 4 (T - 1) + 1
+    for odd T, 4 T for even T (whose first chunk has an even frame count)."""
+    v = AutoencoderKLCogVideoX(block_out_channels=(8, 16, 16, 32), norm_num_groups=4, layers_per_block=1)
+    chunks = [1] if T == 1 else [2 + (T % 2 if i == 0 else 0) for i in range(T // 2)]
+    want = 0
+    for t in chunks:
+        x = torch.zeros(1, 1, t, 2, 2)
+        for _ in range(2):
+            x = dr.upsample3d_nearest(x, True)[:, :, :, :2, :2]
+        want += x.shape[2]
+    assert v.decoded_frames(T) == want == (1 if T == 1 else (4 * (T - 1) + 1 if T % 2 else 4 * T))

@@ -153,6 +153,40 @@ def test_default_width_decode_small_vs_oracle(vae_default, gpu):
     assert torch.equal(d2[1:], vae.decode(z.flip(3).contiguous()).sample)
 
 
+@pytest.mark.parametrize("T,h,w", [(3, 17, 25), (4, 9, 33), (2, 30, 11)])
+def test_default_width_decode_odd_sizes_vs_oracle(vae_default, gpu, T, h, w):
+    """Odd latent grids (136x200, 72x264, 240x88 px: ragged position tiles at every stage, W not a multiple of anything) and even
+    latent frame counts (T = 4 -> chunks (0,2), (2,4): the first chunk has an EVEN frame count, so the temporal upsample takes the
+    all-frames branch, diffusers CogVideoXUpsample3D; T = 2 -> one chunk) through the default-width decoder against the oracle."""
+    vae, cfg, sdf = vae_default
+    g = torch.Generator(device=gpu).manual_seed(100 * T + h)
+    z = torch.randn(1, 16, T, h, w, device=gpu, generator=g).to(BF)
+    dec = vae.decode(z).sample
+    con, ex = _oracle_decode(sdf, cfg, z)
+    assert dec.shape == con.shape and dec.shape[3:] == (8 * h, 8 * w)
+    _check_deep(dec, con, ex, f"default-width decode, latent [{T},{h},{w}]")
+    assert torch.equal(vae.decode_to_frames(z), (dec / 2 + 0.5).clamp(0, 1).float())
+
+
+@pytest.mark.parametrize("Fr,H,W", [(8, 40, 56), (6, 72, 40), (2, 136, 200)])
+def test_default_width_encode_even_frame_counts_vs_oracle(vae_default, gpu, Fr, H, W):
+    """Frame counts that are not 4 k + 1: 8 -> chunks of 4 + 4 (an EVEN first chunk: both temporal average pools take the all-pairs
+    branch), 6 -> one chunk of 6 (remainder folded in: 6 -> 3 -> 1 + 1), 2 -> no full chunk at all (the reference's loop runs zero
+    times and fails on an empty concat, :1199-1210: same error surface here); odd spatial grids."""
+    vae, cfg, sdf = vae_default
+    g = torch.Generator(device=gpu).manual_seed(Fr * H)
+    x = (torch.rand(1, 3, Fr, H, W, device=gpu, generator=g) * 2 - 1).to(BF)
+    if Fr // 4 == 0:
+        with pytest.raises((RuntimeError, ValueError)):
+            vae.encode(x)
+        return
+    post = vae.encode(x).latent_dist
+    con, ex = _oracle_encode(sdf, cfg, x)
+    assert post.mean.shape == con.mean.shape and post.mean.shape[3:] == (H // 8, W // 8)
+    _check_deep(post.mean, con.mean, ex.mean, f"default-width encode mean, {Fr} frames {H}x{W}")
+    _check_deep(post.logvar, con.logvar, ex.logvar, f"default-width encode logvar, {Fr} frames {H}x{W}")
+
+
 def test_default_width_tiled_decode_vs_oracle(vae_default, gpu):
     """enable_tiling() at the default widths: 64 x 96 px tiles (8 x 12 latent) over a 16 x 20 latent -> 3 x 3 ragged tiles, two
     temporal chunks each, through the MFMA conv kernels; blended seams; against the oracle's restatement of tiled_decode."""

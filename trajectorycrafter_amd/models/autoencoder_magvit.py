@@ -548,6 +548,20 @@ class AutoencoderKLCogVideoX(ModelMixin, ConfigMixin):
             return (dec,)
         return DecoderOutput(sample=dec)
 
+    def decoded_frames(self, T: int) -> int:
+        """Frames `decode` returns for T latent frames: the chunks of `_decode` (:1235-1241: remainder folded into the first) each go
+        through log2(temporal_compression_ratio) temporal upsamplings of diffusers CogVideoXUpsample3D(compress_time): 1 frame stays 1,
+        an odd count t > 1 becomes 2 t - 1 (first frame kept), an even count 2 t.  Odd T (the pipeline's 4 k + 1 frame clips):
+        4 (T - 1) + 1; even T: 4 T."""
+        fbs, levels = self.num_latent_frames_batch_size, int(np.log2(self.config.temporal_compression_ratio))
+        chunks = [1] if T == 1 else [fbs + (T % fbs if i == 0 else 0) for i in range(T // fbs)]
+        total = 0
+        for t in chunks:
+            for _ in range(levels):
+                t = t if t == 1 else (2 * t - 1 if t % 2 else 2 * t)
+            total += t
+        return total
+
     @torch.no_grad()
     def decode_to_frames(self, z: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
         """decode + `(x/2+.5).clamp(0,1).float()` of pipeline decode_latents (:514-517), written chunk by chunk."""
@@ -555,7 +569,7 @@ class AutoencoderKLCogVideoX(ModelMixin, ConfigMixin):
         if self.use_tiling and (w > self.tile_latent_min_width or h > self.tile_latent_min_height):
             return self.cl_to_frames(self.decode_cl_bf16(z, scale))
         sf = 2 ** (len(self.config.block_out_channels) - 1)
-        Tout = 1 if T == 1 else (T - 1) * int(self.config.temporal_compression_ratio) + 1
+        Tout = self.decoded_frames(T)
         frames = torch.empty((N, self.config.out_channels, Tout, h * sf, w * sf), device=z.device, dtype=torch.float32)
         self._decode_cl(z, frames, scale)
         return frames
