@@ -137,6 +137,39 @@ def test_pipeline_generator_and_no_cfg(setup):
     assert out.shape == (1, 3, 16, 4, 6) and torch.isfinite(out.float()).all()
 
 
+def test_pipeline_even_frame_count_and_prompt_batch(setup):
+    """Clips that are not 4 k + 1 frames long and batches of prompts: 8 frames 32x48 -> 2 latent frames (one even decode chunk ->
+    8 frames back, one even encode chunk) with TWO prompts (CFG batch 4), conditioning built from pixels by the oracle's encoder,
+    2 DDIM steps + decode against the oracle."""
+    s, tp = setup, setup["tp"]
+    g = torch.Generator().manual_seed(31)
+    video = torch.rand(2, 3, 8, 32, 48, generator=g)
+    mask = (torch.rand(2, 1, 8, 32, 48, generator=g) < 0.3).float() * 255.0
+    reference = video[:, :, :8]
+    torch.manual_seed(123)
+    inpaint, ref = opl.build_conditioning(s["wv"], s["vae_cfg"], video, mask, reference, 32, 48, "fp32")
+    assert inpaint.shape == (4, 2, 17, 4, 6) and ref.shape == (4, 2, 16, 4, 6)
+    pe = torch.randn(2, 10, 32, generator=g).to(BF)
+    ne = torch.randn(2, 10, 32, generator=g).to(BF)
+    lat0 = torch.randn(2, 2, 16, 4, 6, generator=g).to(BF)
+    kw = dict(prompt=None, height=32, width=48, num_frames=8, num_inference_steps=2, guidance_scale=6.0, prompt_embeds=pe,
+              negative_prompt_embeds=ne, latents=lat0, inpaint_latents=inpaint.to(BF), ref_latents=ref.to(BF))
+    lat = s["pipe"](output_type="latent", **kw).videos
+    assert lat.shape == (2, 2, 16, 4, 6)
+    args = (s["wt"], s["tr_cfg"], lat0.float(), pe.float(), ne.float(), inpaint.to(BF).float(), ref.to(BF).float(), 32, 48, 2, 6.0)
+    con, ex = opl.denoise(*args, prec="bf16"), opl.denoise(*args, prec="fp32")
+    _check_deep(lat, con, ex, "pipeline latents, 8 frames (2 latent frames), 2 prompts")
+    frames = s["pipe"](**kw).videos
+    assert frames.shape == (2, 3, 8, 32, 48) and float(frames.min()) >= 0 and float(frames.max()) <= 1
+    _check_deep(frames, opl.decode_latents(s["wv"], s["vae_cfg"], con, prec="bf16"), opl.decode_latents(s["wv"], s["vae_cfg"], ex, prec="fp32"),
+                "pipeline frames, 8 frames, 2 prompts")
+    # the same from pixels through the HIP encoder: shapes and range (the reference-frame posterior is sampled from the device RNG)
+    out = s["pipe"](prompt=None, height=32, width=48, num_frames=8, num_inference_steps=1, guidance_scale=6.0, prompt_embeds=pe,
+                    negative_prompt_embeds=ne, video=video, mask_video=mask, reference=reference,
+                    generator=torch.Generator(device=s["dev"]).manual_seed(1)).videos
+    assert out.shape == (2, 3, 8, 32, 48) and torch.isfinite(out).all()
+
+
 def test_pipeline_error_surface(setup):
     s, tp = setup, setup["tp"]
     pe = tp["prompt_embeds"].to(BF)
