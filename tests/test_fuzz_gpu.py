@@ -1,0 +1,186 @@
+"""Seeded random-shape sweeps of the kernels whose launch geometry depends on the shape (ragged tiles, tail workgroups, strides):
+attention (all loop variants the product can reach), the GEMM with its three epilogues, LayerNorm + modulate, the causal conv.
+Deterministic (fixed seeds), a few dozen shapes each, every element against the oracle with the tolerances of the per-kernel test
+files.  The fixed parametrizations there cover the known edges; these sweeps look for the unknown ones."""
+import math
+import os
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import diffusers_restated as dr
+from oracle import vae as ovae
+from oracle.prec import Prec
+from tests.test_gemm_gpu import _check as gemm_check, _oracle as gemm_oracle
+from tests.test_kernels_gpu import assert_bf16_close, bf, dev
+
+BF = torch.bfloat16
+LOG2E = 1.4426950408889634
+# TCX_FUZZ_SCALE=k multiplies the number of shapes per kernel (and TCX_FUZZ_SEED shifts the seeds) for one-off deep sweeps
+SCALE = int(os.environ.get("TCX_FUZZ_SCALE", "1"))
+SEED = int(os.environ.get("TCX_FUZZ_SEED", "0"))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from trajectorycrafter_amd import ops as _ops
+    return _ops
+
+
+def _attn_shapes(n, seed):
+    r = random.Random(seed)
+    out = []
+    for _ in range(n):
+        D = r.choice([64, 64, 128])
+        B, H = r.randint(1, 3), r.randint(1, 5)
+        Sq = r.choice([1, 2, 31, 32, 33, 255, 256, 257, 300, 511, 513, 700, r.randint(1, 900)])
+        Sk = r.choice([1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 320, 449, 600, r.randint(1, 700)])
+        out.append((D, B, H, Sq, Sk, r.random() < 0.5))
+    return out
+
+
+@pytest.mark.parametrize("D,B,H,Sq,Sk,fused_layout", _attn_shapes(28 * SCALE, 20251 + SEED))
+def test_attention_random_shapes(ops, D, B, H, Sq, Sk, fused_layout):
+    """log2-score product path: exact-tracking loop, bound-centred loop (+ complement), proven bound with and without the tail split,
+    the optional loop bodies (D = 64); q / k / v either contiguous or views into one fused [B, S, 3 H D] projection (Sq == Sk)."""
+    g = torch.Generator().manual_seed(D * 1000003 + Sq * 1009 + Sk)
+    if fused_layout:
+        Sk = Sq
+        qkv = bf(torch.randn(B, Sq, 3 * H * D, generator=g))
+        q, k, v = (t.reshape(B, Sq, H, D) for t in qkv.chunk(3, -1))
+        dqkv = dev(qkv)
+        dq, dk, dv = (t.view(B, Sq, H, D) for t in dqkv.chunk(3, -1))
+    else:
+        q, k, v = (bf(torch.randn(B, s, H, D, generator=g)) for s in (Sq, Sk, Sk))
+        dq, dk, dv = dev(q), dev(k), dev(v)
+    qs = bf(q.float() * (D ** -0.5 * LOG2E))
+    if fused_layout:
+        dq.copy_(dev(qs))
+    else:
+        dq = dev(qs)
+    qt, kt, vt = qs.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)
+    ref = dr.sdpa_log2(Prec("bf16"), qt, kt, vt).transpose(1, 2).contiguous()
+    pr = torch.softmax(torch.matmul(qt, kt.transpose(-1, -2)) * math.log(2.0), dim=-1)
+    bound = 3 * (2.0 ** -9) * torch.matmul(pr, vt.abs()).transpose(1, 2).contiguous()
+    ksq = dev((k.float() ** 2).sum(-1).amax(1).contiguous())
+    outs = {"tracking": ops.attn_fwd(dq, dk, dv, 1.0, log2_scores=True)}
+    if D == 64:
+        outs["bound"] = ops.attn_fwd(dq, dk, dv, 1.0, log2_scores=True, k_sqmax=ksq)
+        M = float((qs.float().norm(dim=-1).amax() * k.float().norm(dim=-1).amax()))
+        if M * 1.002 + 1e-3 < 60:
+            outs["proven"] = ops.attn_fwd(dq, dk, dv, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True)
+            outs["proven, single pass"] = ops.attn_fwd(dq, dk, dv, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, split_tail=False)
+            outs["16x16x32 body"] = ops.attn_fwd(dq, dk, dv, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=True)
+            outs["4-wave body"] = ops.attn_fwd(dq, dk, dv, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=4)
+    else:
+        outs["bound"] = ops.attn_fwd(dq, dk, dv, 1.0, log2_scores=True, k_sqmax=ksq)
+    for name, o in outs.items():
+        assert o.shape == (B, Sq, H, D), name
+        try:
+            # mean criterion: output rounding alone averages up to 2^-9 |o| (mean_frac 0.25); P is rounded once on each side against
+            # different exponent origins (running max vs the bound), which adds its share on short key ranges -> 0.4
+            assert_bf16_close(o, ref, extra=bound, mean_frac=0.4)
+        except AssertionError as e:
+            raise AssertionError(f"{name}: {e}") from None
+
+
+def _gemm_shapes(n, seed):
+    r = random.Random(seed)
+    out = []
+    for _ in range(n):
+        M = r.choice([1, 2, 7, 8, 9, 255, 256, 257, 300, 511, 1000, r.randint(1, 1500)])
+        N = 8 * r.choice([1, 8, 16, 31, 32, 33, 64, 65, 96, 128, 240, r.randint(1, 400)])
+        K = 8 * r.choice([1, 4, 15, 16, 17, 32, 48, 64, 100, 128, r.randint(1, 300)])
+        out.append((M, N, K, r.randint(0, 2)))
+    return out
+
+
+@pytest.mark.parametrize("M,N,K,epi", _gemm_shapes(36 * SCALE, 777 + SEED))
+def test_gemm_random_shapes(ops, M, N, K, epi):
+    g = torch.Generator().manual_seed(M * 31 + N * 7 + K + epi)
+    x = torch.randn(M, K, generator=g).to(BF)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    b = torch.randn(N, generator=g).to(BF)
+    kw, okw = {}, {}
+    xd = x.cuda()
+    if epi == 2:
+        res = torch.randn(M, N, generator=g).to(BF)
+        okw["res"] = res
+        if M % 2 == 0:                                     # gated: two batch items of M / 2 rows, the first `tl` rows take gate_t
+            gv, gt = torch.randn(2, N, generator=g).to(BF), torch.randn(2, N, generator=g).to(BF)
+            tl = min(M // 2, g.initial_seed() % 7)
+            kw.update(res=res.cuda().view(2, M // 2, N), gate_v=gv.cuda(), gate_t=gt.cuda(), text_len=tl)
+            okw.update(gv=gv, gt=gt, rpb=M // 2, tl=tl)
+            xd = xd.view(2, M // 2, K)
+        else:
+            kw["res"] = res.cuda()
+    got = ops.gemm_bf16(xd, w.cuda(), b.cuda(), epilogue=epi, **kw)
+    gemm_check(got.reshape(M, N), gemm_oracle(x, w, b, epi, **okw), scale=2.0)
+
+
+def _ln_shapes(n, seed):
+    r = random.Random(seed)
+    return [(8 * r.choice([8, 16, 64, 100, 240, 384, 512, 640, 1000, 1024, r.randint(1, 1024)]), r.choice([1, 2, 3, 50, 257, r.randint(1, 700)]),
+             r.randint(1, 3), r.random() < 0.6) for _ in range(n)]
+
+
+@pytest.mark.parametrize("C,rows,B,modulated", _ln_shapes(20 * SCALE, 99 + SEED))
+def test_layernorm_modulate_random_shapes(ops, C, rows, B, modulated):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(C + rows)
+    x = bf(torch.randn(B, rows, C, generator=g) * 1.7 + 0.3)
+    gamma, beta = bf(1 + 0.2 * torch.randn(C, generator=g)), bf(0.1 * torch.randn(C, generator=g))
+    ref = F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), 1e-5)
+    if modulated:
+        tl = min(rows, (C + rows) % 5)
+        mod = bf(torch.randn(B, 4 * C, generator=g) * 0.5)
+        sv, cv, st, ct = mod.chunk(4, dim=1)
+        sel = (torch.arange(rows)[None, :, None] < tl)
+        ref = ref * (1 + torch.where(sel, ct.float()[:, None], cv.float()[:, None])) + torch.where(sel, st.float()[:, None], sv.float()[:, None])
+        dm = dev(mod)
+        dsv, dcv, dst, dct = dm.chunk(4, dim=1)
+        y = ops.layernorm_modulate(dev(x), dev(gamma), dev(beta), 1e-5, dsv, dcv, dst, dct, text_len=tl)
+    else:
+        y = ops.layernorm_modulate(dev(x), dev(gamma), dev(beta), 1e-5)
+    assert_bf16_close(y, ref, atol=2e-3)
+
+
+def _conv_shapes(n, seed):
+    r = random.Random(seed)
+    out = []
+    for _ in range(n):
+        Cin, Cout = r.choice([16, 32, 64, 128, 256]), r.choice([3, 16, 32, 64, 128, 256])
+        out.append((Cin, Cout, r.randint(1, 3), r.randint(1, 21), r.randint(1, 23), r.choice([(3, 3, 3), (1, 1, 1), (3, 3, 3)]), r.random() < 0.5))
+    return out
+
+
+@pytest.mark.parametrize("Cin,Cout,T,H,W,ksz,with_res", _conv_shapes(24 * SCALE, 4242 + SEED))
+def test_causal_conv_random_shapes(ops, Cin, Cout, T, H, W, ksz, with_res):
+    """`tcx_conv3d_cl` on random (channels, frames, height, width) — every dispatch route (MFMA wide / tall, narrow, register-staged)
+    with and without the fused residual, first chunk (frame replication) then a second chunk through the conv cache."""
+    from tests.test_kernels_gpu import from_cl, to_cl, w_cl
+    g = torch.Generator().manual_seed(Cin * 131 + Cout * 17 + H * W + T)
+    p = Prec("bf16")
+    kt = ksz[0]
+    w = bf(torch.randn(Cout, Cin, *ksz, generator=g) / math.sqrt(Cin * ksz[0] * ksz[1] * ksz[2]))
+    b = bf(torch.randn(Cout, generator=g) * 0.1)
+    sd = {"c.conv.weight": w.float(), "c.conv.bias": b.float()}
+    x1, x2 = bf(torch.randn(1, Cin, T, H, W, generator=g)), bf(torch.randn(1, Cin, 2, H, W, generator=g))
+    r1 = bf(torch.randn(1, Cout, T, H, W, generator=g)) if with_res else None
+    cache = {}
+    ref1 = ovae.causal_conv3d(p, sd, "c.", x1.float(), cache, res=None if r1 is None else r1.float())
+    ref2 = ovae.causal_conv3d(p, sd, "c.", x2.float(), cache)
+    dw, db = dev(w_cl(w)), dev(b)
+    y1 = ops.conv3d_cl(dev(to_cl(x1)), dw, db, res=None if r1 is None else dev(to_cl(r1)))
+    assert_bf16_close(from_cl(y1), ref1, atol=2e-3)
+    if kt > 1:
+        dcache = dev(to_cl(x1))[:, -(kt - 1):].contiguous() if T >= kt - 1 else torch.cat([dev(to_cl(x1))[:, :1]] * (kt - 1 - T) + [dev(to_cl(x1))], 1).contiguous()
+        y2 = ops.conv3d_cl(dev(to_cl(x2)), dw, db, cache=dcache)
+    else:
+        y2 = ops.conv3d_cl(dev(to_cl(x2)), dw, db)
+    assert_bf16_close(from_cl(y2), ref2, atol=2e-3)
