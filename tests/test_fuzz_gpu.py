@@ -228,3 +228,43 @@ def test_forward_warp_random_shapes(b, h, w, with_mask, clean, per_frame):
             rel = (err / (1 + e.abs())).flatten().sort(descending=True).values        # corner weights of the order of the fp32 position
             assert float(rel[3]) <= 2e-2, rel[:6].tolist()                            # rounding (1e-5 px) mixes its sources arbitrarily
     assert float(warped.min()) >= -1.0 and float(warped.max()) <= 1.0
+
+
+def _vae_shapes(n, seed):
+    r = random.Random(seed)
+    return [(r.randint(1, 7), r.randint(1, 11), r.randint(1, 13), r.randint(1, 2)) for _ in range(n)]
+
+
+@pytest.fixture(scope="module")
+def tiny_vae(golden):
+    import ast
+    from tests.test_models_gpu import _weights
+    from trajectorycrafter_amd.models.autoencoder_magvit import AutoencoderKLCogVideoX
+    t, meta = golden("vae_tiny.safetensors")
+    cfg = ast.literal_eval(meta["config"])
+    sd = _weights(t)
+    vae = AutoencoderKLCogVideoX(**cfg)
+    vae.load_state_dict(sd, strict=True)
+    return vae.to("cuda:0", BF).eval(), cfg, {k: v.float() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("T,h,w,N", _vae_shapes(8 * SCALE, 31337 + SEED))
+def test_vae_decode_encode_random_sizes(tiny_vae, T, h, w, N):
+    """The composed decoder / encoder (tiny widths: conv.hip's register-staged kernel, GroupNorm / SpatialNorm apply with the zq
+    gather, folded upsample / stride-2 gathers, temporal average pool, conv caches over the chunks) on random latent sizes — single
+    rows / columns, even and odd frame counts, batch 1 / 2 — against the oracle."""
+    from tests.test_models_gpu import _check_deep
+    vae, cfg, sdf = tiny_vae
+    g = torch.Generator().manual_seed(T * 10007 + h * 101 + w)
+    z = torch.randn(N, 16, T, h, w, generator=g).to(BF)
+    dec = vae.decode(z.cuda()).sample
+    con, ex = ovae.vae_decode(sdf, cfg, z.float(), prec="bf16"), ovae.vae_decode(sdf, cfg, z.float(), prec="fp32")
+    assert dec.shape == con.shape == (N, 3, vae.decoded_frames(T), 8 * h, 8 * w)
+    _check_deep(dec, con, ex, f"tiny decode [{N},{T},{h},{w}]", record=False)
+    assert torch.equal(vae.decode_to_frames(z.cuda()), (dec / 2 + 0.5).clamp(0, 1).float())
+    Fr = 1 if T == 1 else 4 * (T - 1) + 1 if T % 2 else 4 * T
+    x = (torch.rand(N, 3, Fr, 8 * h, 8 * w, generator=g) * 2 - 1).to(BF)
+    post = vae.encode(x.cuda()).latent_dist
+    pc, pe = ovae.vae_encode(sdf, cfg, x.float(), prec="bf16"), ovae.vae_encode(sdf, cfg, x.float(), prec="fp32")
+    assert post.mean.shape == pc.mean.shape
+    _check_deep(post.mean, pc.mean, pe.mean, f"tiny encode mean [{N},{Fr},{8 * h},{8 * w}]", record=False)

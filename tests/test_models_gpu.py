@@ -49,7 +49,7 @@ def record_parity(rec: dict) -> None:
         pass
 
 
-def _check_deep(got, contract, exact, what):
+def _check_deep(got, contract, exact, what, record=True):
     """Deep bf16 pipelines (many rounded layers) diverge element-wise even between two correct
     implementations, because a one-ulp flip early on is amplified downstream.  The criterion that
     still catches real bugs: measured against the reference's own fp32 output (`exact`, from the golden
@@ -68,7 +68,8 @@ def _check_deep(got, contract, exact, what):
            "hip_vs_fp32": {"max": float(e_hip.max()), "mean": float(e_hip.mean()), "p99.9": q(e_hip), "inside_rtol1e-3_atol1e-4": inside(got, exact)},
            "contract_vs_fp32": {"max": float(e_con.max()), "mean": float(e_con.mean()), "p99.9": q(e_con), "inside_rtol1e-3_atol1e-4": inside(contract, exact)},
            "hip_vs_contract": {"max": float(e_hc.max()), "mean": float(e_hc.mean()), "inside_rtol1e-3_atol1e-4": inside(got, contract)}}
-    record_parity(rec)
+    if record:
+        record_parity(rec)
     assert float(e_hip.mean()) <= 1.5 * float(e_con.mean()) + 1e-5, msg
     assert q(e_hip) <= 2.0 * q(e_con) + 1e-4, msg
     assert float(e_hc.mean()) <= 2.0 * float(e_con.mean()) + 1e-5, msg
