@@ -268,3 +268,54 @@ def test_vae_decode_encode_random_sizes(tiny_vae, T, h, w, N):
     pc, pe = ovae.vae_encode(sdf, cfg, x.float(), prec="bf16"), ovae.vae_encode(sdf, cfg, x.float(), prec="fp32")
     assert post.mean.shape == pc.mean.shape
     _check_deep(post.mean, pc.mean, pe.mean, f"tiny encode mean [{N},{Fr},{8 * h},{8 * w}]", record=False)
+
+
+def _tr_shapes(n, seed):
+    r = random.Random(seed)
+    return [(r.randint(1, 3), r.randint(1, 5), 2 * r.randint(1, 9), 2 * r.randint(1, 11), r.randint(1, 3), r.choice([1, 3, 10, 17]), r.random() < 0.8)
+            for _ in range(n)]
+
+
+@pytest.fixture(scope="module")
+def tiny_transformers(golden):
+    import ast
+    from tests.test_models_gpu import _weights
+    from trajectorycrafter_amd.models.crosstransformer3d import CrossTransformer3DModel
+    t, meta = golden("transformer_tiny.safetensors")
+    cfg = ast.literal_eval(meta["config"])
+    sd = _weights(t)
+    out = {}
+    for rotary in (True, False):
+        c = dict(cfg, use_rotary_positional_embeddings=rotary)
+        m = CrossTransformer3DModel(**c)
+        m.load_state_dict(sd, strict=True)
+        out[rotary] = (m.to("cuda:0", BF).eval(), c)
+    return out, {k: v.float() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("B,T,h,w,Tr,text_len,rotary", _tr_shapes(16 * SCALE, 90210 + SEED))
+def test_transformer_forward_random_sizes(tiny_transformers, B, T, h, w, Tr, text_len, rotary):
+    """`CrossTransformer3DModel.forward` (2 blocks + cross-attention, 2 heads x 64) on random batch / frame / grid sizes, reference-frame
+    counts and text lengths (patchify, the generic q/k LayerNorm + RoPE kernel, ragged attention tiles on both attentions, skinny and
+    ragged GEMMs, unpatchify), rotary and non-rotary position handling, against the oracle."""
+    from oracle import transformer as otr
+    from oracle.pipeline import prepare_rotary
+    from tests.test_models_gpu import _check_deep
+    models, sdf = tiny_transformers
+    if not rotary:
+        text_len, T = 10, min(T, 3)                         # the non-rotary view needs text_seq_length == max_text_seq_length (:759-765)
+    model, cfg = models[rotary]
+    g = torch.Generator().manual_seed(B * 7919 + T * 1009 + h * 31 + w + text_len)
+    hs, enc = torch.randn(B, T, 16, h, w, generator=g).to(BF), torch.randn(B, text_len, 32, generator=g).to(BF)
+    inp, cross = torch.randn(B, T, 17, h, w, generator=g).to(BF), torch.randn(B, Tr, 16, h, w, generator=g).to(BF)
+    ts = torch.full((B,), 321)
+    rot = None
+    if rotary:
+        cos, sin = prepare_rotary(8 * h, 8 * w, T, 2, 64)
+        rot = (cos, sin)
+    out = model(hs.cuda(), enc.cuda(), ts.cuda(), inpaint_latents=inp.cuda(), cross_latents=cross.cuda(),
+                image_rotary_emb=None if rot is None else (cos.cuda(), sin.cuda()), return_dict=False)[0]
+    args = (sdf, cfg, hs.float(), enc.float(), ts, inp.float(), cross.float(), rot)
+    con, ex = otr.transformer_forward(*args, prec="bf16"), otr.transformer_forward(*args, prec="fp32")
+    assert out.shape == hs.shape
+    _check_deep(out, con, ex, f"tiny transformer B={B} T={T} {h}x{w} ref={Tr} text={text_len} rotary={rotary}", record=False)
