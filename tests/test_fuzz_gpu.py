@@ -319,3 +319,42 @@ def test_transformer_forward_random_sizes(tiny_transformers, B, T, h, w, Tr, tex
     con, ex = otr.transformer_forward(*args, prec="bf16"), otr.transformer_forward(*args, prec="fp32")
     assert out.shape == hs.shape
     _check_deep(out, con, ex, f"tiny transformer B={B} T={T} {h}x{w} ref={Tr} text={text_len} rotary={rotary}", record=False)
+
+
+def _cond_shapes(n, seed):
+    r = random.Random(seed)
+    return [(r.randint(1, 2), r.choice([1, 4, 5, 8, 9, 12, 13]), 16 * r.randint(1, 4), 16 * r.randint(1, 5), r.randint(1, 5), r.random() < 0.5) for _ in range(n)]
+
+
+@pytest.mark.parametrize("B,Fr,H,W,Fref,resize", _cond_shapes(8 * SCALE, 2718 + SEED))
+def test_conditioning_from_pixels_random_sizes(tiny_vae, tiny_transformers, B, Fr, H, W, Fref, resize):
+    """`TrajCrafter_Pipeline._build_conditioning` (preprocess, mask binarisation, masked-video VAE encode `.mode()`, trilinear mask
+    resize, reference-frame encode) on random clip lengths / sizes / reference-frame counts — with and without a source resolution
+    that differs from the sample size (the preprocess resize) — against the oracle (deterministic parts), then ONE full pipeline step
+    from those pixels (shapes, range, finiteness)."""
+    from oracle import pipeline as opl
+    from tests.test_models_gpu import _check_deep
+    from trajectorycrafter_amd.models.pipeline_trajectorycrafter import TrajCrafter_Pipeline
+    vae, vcfg, vsd = tiny_vae
+    models, _ = tiny_transformers
+    Fref = min(Fref, Fr)
+    if Fr < 4 and Fr != 1 or Fref < 4 and Fref != 1:
+        pytest.skip("fewer than 4 (but more than 1) frames: the reference's encode loop runs zero times (:1199-1210)")
+    pipe = TrajCrafter_Pipeline(None, None, vae, models[True][0])
+    g = torch.Generator().manual_seed(Fr * 1000 + H + W)
+    sh, sw = (H + 8, W + 16) if resize else (H, W)
+    video = torch.rand(B, 3, Fr, sh, sw, generator=g)
+    mask = (torch.rand(B, 1, Fr, sh, sw, generator=g) < 0.3).float() * 255.0
+    reference = video[:, :, :Fref]
+    dev_ = torch.device("cuda:0")
+    inpaint, ref_lat = pipe._build_conditioning(video, mask, reference, H, W, True, BF, dev_)
+    T = (Fr - 1) // 4 + 1
+    assert inpaint.shape == (B, T, 17, H // 8, W // 8) and ref_lat.shape[0] == B and ref_lat.shape[2:] == (16, H // 8, W // 8)
+    ex, _ = opl.build_conditioning(vsd, vcfg, video, mask, reference, H, W, "fp32", do_cfg=False)
+    con, _ = opl.build_conditioning(vsd, vcfg, video, mask, reference, H, W, "bf16", do_cfg=False)
+    _check_deep(inpaint, con, ex, f"inpaint latents B={B} {Fr}f {H}x{W} from {sh}x{sw}", record=False)
+    pe = torch.randn(B, 10, 32, generator=g).to(BF)
+    out = pipe(prompt=None, height=H, width=W, num_frames=Fr, num_inference_steps=1, guidance_scale=6.0, prompt_embeds=pe,
+               negative_prompt_embeds=pe.flip(0), video=video, mask_video=mask, reference=reference,
+               generator=torch.Generator(device=dev_).manual_seed(3)).videos
+    assert out.shape == (B, 3, vae.decoded_frames(T), H, W) and torch.isfinite(out).all() and 0 <= float(out.min()) and float(out.max()) <= 1
