@@ -133,7 +133,7 @@ def test_route_at_default_widths(gpu):
     assert r(Cin=32, Cout=32, k=(3, 3, 3)) == IGEMM and r(Cin=16, Cout=8, k=(3, 3, 3)) == IGEMM
 
 
-def test_default_width_decode_small_vs_oracle(vae_default, gpu):
+def test_default_width_decode_small_vs_oracle(vae_default, gpu, fast_oracle_convs):
     """[1,16,5,8,12] -> 17 frames 64x96: chunk (0,3) with frame-0 replication, chunk (3,5) with the conv caches, then T == 1."""
     vae, cfg, sdf = vae_default
     g = torch.Generator(device=gpu).manual_seed(5)
@@ -154,7 +154,7 @@ def test_default_width_decode_small_vs_oracle(vae_default, gpu):
 
 
 @pytest.mark.parametrize("T,h,w", [(3, 17, 25), (4, 9, 33), (2, 30, 11)])
-def test_default_width_decode_odd_sizes_vs_oracle(vae_default, gpu, T, h, w):
+def test_default_width_decode_odd_sizes_vs_oracle(vae_default, gpu, fast_oracle_convs, T, h, w):
     """Odd latent grids (136x200, 72x264, 240x88 px: ragged position tiles at every stage, W not a multiple of anything) and even
     latent frame counts (T = 4 -> chunks (0,2), (2,4): the first chunk has an EVEN frame count, so the temporal upsample takes the
     all-frames branch, diffusers CogVideoXUpsample3D; T = 2 -> one chunk) through the default-width decoder against the oracle."""
@@ -169,7 +169,7 @@ def test_default_width_decode_odd_sizes_vs_oracle(vae_default, gpu, T, h, w):
 
 
 @pytest.mark.parametrize("Fr,H,W", [(8, 40, 56), (6, 72, 40), (2, 136, 200)])
-def test_default_width_encode_even_frame_counts_vs_oracle(vae_default, gpu, Fr, H, W):
+def test_default_width_encode_even_frame_counts_vs_oracle(vae_default, gpu, fast_oracle_convs, Fr, H, W):
     """Frame counts that are not 4 k + 1: 8 -> chunks of 4 + 4 (an EVEN first chunk: both temporal average pools take the all-pairs
     branch), 6 -> one chunk of 6 (remainder folded in: 6 -> 3 -> 1 + 1), 2 -> no full chunk at all (the reference's loop runs zero
     times and fails on an empty concat, :1199-1210: same error surface here); odd spatial grids."""
@@ -187,7 +187,7 @@ def test_default_width_encode_even_frame_counts_vs_oracle(vae_default, gpu, Fr, 
     _check_deep(post.logvar, con.logvar, ex.logvar, f"default-width encode logvar, {Fr} frames {H}x{W}")
 
 
-def test_default_width_tiled_decode_vs_oracle(vae_default, gpu):
+def test_default_width_tiled_decode_vs_oracle(vae_default, gpu, fast_oracle_convs):
     """enable_tiling() at the default widths: 64 x 96 px tiles (8 x 12 latent) over a 16 x 20 latent -> 3 x 3 ragged tiles, two
     temporal chunks each, through the MFMA conv kernels; blended seams; against the oracle's restatement of tiled_decode."""
     vae, cfg, sdf = vae_default
