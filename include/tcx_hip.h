@@ -203,6 +203,24 @@ int tcx_cfg_ddim_cog_step(const void* u, const void* c, const void* x, void* out
 int tcx_cfg_sigma_step(const void* u, const void* c, const void* x, void* out, int64_t n, float guidance, int32_t kind,
                        const float* coef, const float* hist_in, float* hist_out, const float* noise, int32_t pred_dtype, void* stream);
 
+/* ---- K10d: the same fusion for "PNDM" (diffusers PNDMScheduler, v-prediction; 12 Runge-Kutta evaluations, then 4th-order linear
+ * multistep).  mo = u + g (c - u); `coef` is a HOST array of 6 floats {w, sqrt(a_t), sqrt(1 - a_t), sqrt(a_prev / a_t), a_prev - a_t,
+ * a_t sqrt(1 - a_prev) + sqrt(a_t (1 - a_t) a_prev)} (the scheduler's 0-dim fp32 scalars); all history tensors are fp32, n elements.
+ *   TCX_PNDM_PRK_FIRST  cur_out = (cur_in ? cur_in : 0) + w mo;  mo_out = mo;  eff = mo            (w = 1/6)
+ *   TCX_PNDM_PRK_MID    cur_out = cur_in + w mo;                             eff = mo            (w = 1/3)
+ *   TCX_PNDM_PRK_LAST   eff = cur_in + w mo                                                      (w = 1/6)
+ *   TCX_PNDM_PLMS4      mo_out = mo;  eff = (1/24)(((55 mo - 59 e1) + 37 e2) - 9 e3)              (e1 newest)
+ *   then eps = coef[1] eff + bf16r(coef[2] x);  out = bf16r( bf16r(coef[3] x) - (coef[4] eps) / coef[5] ),  x = the bf16 sample the
+ *   library hands `_get_prev_sample` (the group's first sample during the Runge-Kutta evaluations).
+ * Replaces: models/pipeline_trajectorycrafter.py:1117,1157-1167,1178 with PNDMScheduler.step (demo.py:651). */
+#define TCX_PNDM_PRK_FIRST 0
+#define TCX_PNDM_PRK_MID 1
+#define TCX_PNDM_PRK_LAST 2
+#define TCX_PNDM_PLMS4 3
+int tcx_cfg_pndm_step(const void* u, const void* c, const void* x, void* out, int64_t n, float guidance, int32_t mode,
+                      const float* coef, const float* e1, const float* e2, const float* e3, const float* cur_in, float* cur_out,
+                      float* mo_out, int32_t pred_dtype, void* stream);
+
 /* y = bf16r(x / d), n bf16 elements: `scheduler.scale_model_input` of the Euler samplers (x / sqrt(sigma^2 + 1); a bf16 tensor
  * divided by a 0-dim fp32 tensor stays bf16).  Replaces: models/pipeline_trajectorycrafter.py:1099-1101 for those schedulers. */
 int tcx_div_bf16(const void* x, void* y, int64_t n, float d, void* stream);

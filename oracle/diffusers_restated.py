@@ -631,3 +631,89 @@ class DPMSolverMultistepScheduler(_SigmaScheduler):
         if self.lower_order_nums < self.solver_order:
             self.lower_order_nums += 1
         return prev
+
+
+class PNDMScheduler:
+    """diffusers `PNDMScheduler` ("PNDM" of demo.py:647-654) as `from_pretrained` builds it from the CogVideoX scheduler config:
+    scaled-linear betas (NO zero-terminal-SNR rescale: the class has no such option and ignores the key), v_prediction, trailing
+    spacing, set_alpha_to_one = True, skip_prk_steps = False (class default) -> the schedule opens with 12 Runge-Kutta evaluations
+    (3 groups of 4 over the last 3 intervals ... 999 -> 939) followed by 47 fourth-order linear-multistep (PLMS) steps: 59 model
+    evaluations for num_inference_steps = 50; `timesteps` is that 59-long list and the pipeline loops over it.  Restated from the
+    published algorithm (parity unpinned).  State: `ets` (up to 4 past model outputs, fp32), the running Runge-Kutta sum, the sample at
+    the start of a Runge-Kutta group.
+
+        eps   = sqrt(a_t) v + bf16r(sqrt(1 - a_t) x)                     (v_prediction inside `_get_prev_sample`; x is the un-upcast sample)
+        x_prev = bf16r(sqrt(a_prev / a_t) x) - (a_prev - a_t) eps / (a_t sqrt(1 - a_prev) + sqrt(a_t (1 - a_t) a_prev))
+    """
+    order = 1
+    init_noise_sigma = 1.0
+    pndm_order = 4
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 prediction_type="v_prediction", timestep_spacing="trailing", set_alpha_to_one=True, steps_offset=0,
+                 skip_prk_steps=False, **ignored):
+        assert beta_schedule == "scaled_linear" and prediction_type == "v_prediction" and not skip_prk_steps
+        self.num_train_timesteps, self.timestep_spacing, self.steps_offset = num_train_timesteps, timestep_spacing, steps_offset
+        self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.timesteps = None
+
+    def scale_model_input(self, p: Prec, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        N, n = self.num_train_timesteps, num_inference_steps
+        self.num_inference_steps = n
+        if self.timestep_spacing == "trailing":
+            ts = np.round(np.arange(N, 0, -N / n))[::-1].astype(np.int64) - 1
+        elif self.timestep_spacing == "leading":
+            ts = (np.arange(0, n) * (N // n)).round().astype(np.int64) + self.steps_offset
+        else:
+            raise ValueError(self.timestep_spacing)
+        self._timesteps = ts
+        prk = np.array(ts[-self.pndm_order:]).repeat(2) + np.tile(np.array([0, N // n // 2]), self.pndm_order)
+        self.prk_timesteps = (prk[:-1].repeat(2)[1:-1])[::-1].copy()
+        self.plms_timesteps = ts[:-3][::-1].copy()
+        self.timesteps = torch.from_numpy(np.concatenate([self.prk_timesteps, self.plms_timesteps]).astype(np.int64))
+        self.ets, self.counter, self.cur_model_output, self.cur_sample = [], 0, 0, None
+
+    def prev_coeffs(self, timestep: int, prev_timestep: int):
+        """(sqrt(a_t), sqrt(1 - a_t), sample_coeff, a_prev - a_t, denominator) as 0-dim fp32 tensors, the library's expressions."""
+        a = self.alphas_cumprod[timestep]
+        ap = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b, bp = 1 - a, 1 - ap
+        return a ** 0.5, b ** 0.5, (ap / a) ** 0.5, ap - a, a * bp ** 0.5 + (a * b * ap) ** 0.5
+
+    def _get_prev_sample(self, p: Prec, sample, timestep, prev_timestep, model_output):
+        sa, sb, sc, diff, denom = self.prev_coeffs(int(timestep), int(prev_timestep))
+        s = sample.float()
+        model_output = sa * model_output + p.R(sb * s)
+        return p.R(sc * s) - diff * model_output / denom
+
+    def step(self, p: Prec, model_output: torch.Tensor, timestep, sample: torch.Tensor):
+        N, n = self.num_train_timesteps, self.num_inference_steps
+        timestep = int(timestep)
+        if self.counter < len(self.prk_timesteps):                       # step_prk
+            diff_to_prev = 0 if self.counter % 2 else N // n // 2
+            prev_timestep = timestep - diff_to_prev
+            timestep = int(self.prk_timesteps[self.counter // 4 * 4])
+            if self.counter % 4 == 0:
+                self.cur_model_output = self.cur_model_output + 1 / 6 * model_output
+                self.ets.append(model_output)
+                self.cur_sample = sample
+            elif (self.counter - 1) % 4 == 0 or (self.counter - 2) % 4 == 0:
+                self.cur_model_output = self.cur_model_output + 1 / 3 * model_output
+            else:
+                model_output = self.cur_model_output + 1 / 6 * model_output
+                self.cur_model_output = 0
+            prev = self._get_prev_sample(p, self.cur_sample, timestep, prev_timestep, model_output)
+        else:                                                            # step_plms (with the three Runge-Kutta outputs in `ets`)
+            assert len(self.ets) >= 3
+            prev_timestep = timestep - N // n
+            self.ets = self.ets[-3:] + [model_output]
+            e = self.ets
+            model_output = (1 / 24) * (55 * e[-1] - 59 * e[-2] + 37 * e[-3] - 9 * e[-4])
+            prev = self._get_prev_sample(p, sample, timestep, prev_timestep, model_output)
+        self.counter += 1
+        return prev

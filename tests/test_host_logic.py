@@ -73,8 +73,8 @@ def test_cog_scheduler_matches_oracle_and_sampler_table(tmp_path):
     (d / "scheduler_config.json").write_text(json.dumps({"_class_name": "CogVideoXDDIMScheduler", "snr_shift_scale": 3.0,
                                                          "clip_sample_range": 1.0, "sample_max_value": 1.0, "trained_betas": None}))
     assert make_scheduler("DDIM_Cog", str(tmp_path)).config.snr_shift_scale == 3.0
-    with pytest.raises(NotImplementedError, match="not built"):
-        make_scheduler("PNDM", None)
+    from trajectorycrafter_amd.scheduler import PNDMScheduler
+    assert type(make_scheduler("PNDM", None)) is PNDMScheduler
     with pytest.raises(ValueError, match="unknown sampler"):
         make_scheduler("LCM", None)
 
@@ -426,3 +426,25 @@ def test_decoded_frame_count_matches_the_chunked_temporal_upsampling(T):
             x = dr.upsample3d_nearest(x, True)[:, :, :, :2, :2]
         want += x.shape[2]
     assert v.decoded_frames(T) == want == (1 if T == 1 else (4 * (T - 1) + 1 if T % 2 else 4 * T))
+
+
+def test_pndm_schedule_and_coefficients_match_oracle():
+    """"PNDM" (demo.py:651): the 59-long evaluation schedule of 50 inference steps (12 Runge-Kutta evaluations + 47 multistep updates) and
+    every `_get_prev_sample` coefficient set of the product scheduler == the oracle's restatement, bit for bit; add_noise as DDIM's."""
+    from trajectorycrafter_amd.scheduler import PNDMScheduler
+    a, b = PNDMScheduler(), dr.PNDMScheduler()
+    assert torch.equal(a.alphas_cumprod, b.alphas_cumprod) and float(a.alphas_cumprod[-1]) > 1e-3          # no zero-terminal-SNR rescale
+    for n in (4, 10, 25, 50):
+        a.set_timesteps(n), b.set_timesteps(n)
+        assert a.timesteps.dtype == torch.int64 and torch.equal(a.timesteps, b.timesteps) and len(a.timesteps) == n + 9
+    assert a.timesteps[:13].tolist() == [999, 989, 989, 979, 979, 969, 969, 959, 959, 949, 949, 939, 939] and a.timesteps[-1] == 19
+    for t, pt in ((999, 989), (999, 979), (939, 919), (19, -1)):
+        assert a.prev_coeffs(t, pt) == [float(v) for v in b.prev_coeffs(t, pt)]
+    with pytest.raises(ValueError, match="at least"):
+        a.set_timesteps(3)
+    with pytest.raises(ValueError, match="skip_prk_steps"):
+        PNDMScheduler(skip_prk_steps=True)
+    g = torch.Generator().manual_seed(8)
+    x0, nz = torch.randn(1, 3, 16, 4, 6, generator=g).to(torch.bfloat16), torch.randn(1, 3, 16, 4, 6, generator=g).to(torch.bfloat16)
+    ddim_like = DDIMScheduler(rescale_betas_zero_snr=False)
+    assert torch.equal(a.add_noise(x0, nz, torch.tensor([499])), ddim_like.add_noise(x0, nz, torch.tensor([499])))

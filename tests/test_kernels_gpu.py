@@ -445,6 +445,42 @@ def test_cfg_sigma_step_matches_oracle(ops, name):
         ps.fused_cfg_step(dev(u), None, dev(x), 1.0, 998)
 
 
+def test_cfg_pndm_step_matches_oracle(ops):
+    """`tcx_cfg_pndm_step` ("PNDM") through the product scheduler's `fused_cfg_step`: the whole 59-evaluation trajectory of a 50-step
+    schedule (12 Runge-Kutta evaluations, 47 multistep updates) with CFG 6 on fixed random model outputs, against the oracle's restated
+    PNDMScheduler under the bf16 contract — the kernel applies the library's fp32 operations in their order: bit-equal latents after
+    every evaluation.  Out-of-order timesteps are refused (the schedule is stateful)."""
+    from trajectorycrafter_amd.scheduler import PNDMScheduler
+    g = torch.Generator().manual_seed(4711)
+    p = Prec("bf16")
+    for n_steps, pred_bf16 in ((50, False), (6, True)):
+        ps, s = PNDMScheduler(), dr.PNDMScheduler()
+        ps.set_timesteps(n_steps), s.set_timesteps(n_steps)
+        x = bf(torch.randn(1, 5, 16, 6, 10, generator=g))
+        xd = dev(x)
+        for i, t in enumerate(s.timesteps.tolist()):
+            pred = torch.randn(2, 5, 16, 6, 10, generator=g)
+            if pred_bf16:
+                pred = bf(pred)
+            u, c = pred.float().chunk(2)
+            ref = p.R(s.step(p, u + 6.0 * (c - u), t, x))
+            d = dev(pred)
+            got = ps.fused_cfg_step(d[:1], d[1:], xd, 6.0, t)
+            assert got.dtype == torch.bfloat16 and torch.equal(got.float().cpu(), ref), (n_steps, i, t, float((got.float().cpu() - ref).abs().max()))
+            x, xd = ref.to(torch.bfloat16), got
+        with pytest.raises(RuntimeError, match="more steps"):
+            ps.fused_cfg_step(d[:1], d[1:], xd, 6.0, 19)
+    ps = PNDMScheduler()
+    ps.set_timesteps(10)
+    with pytest.raises(ValueError, match="expects timestep"):
+        ps.fused_cfg_step(d[:1], d[1:], xd, 6.0, 899)
+    # the diffusers-shaped step (no guidance)
+    ps, s = PNDMScheduler(), dr.PNDMScheduler()
+    ps.set_timesteps(8), s.set_timesteps(8)
+    u = torch.randn(1, 5, 16, 6, 10, generator=g)
+    assert torch.equal(ps.step(dev(u), 999, xd)[0].float().cpu(), p.R(s.step(p, u, 999, xd.float().cpu())))
+
+
 # ----------------------------------------------------------------------------- VAE kernels
 def to_cl(x):
     return x.permute(0, 2, 3, 4, 1).contiguous()

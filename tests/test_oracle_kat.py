@@ -348,3 +348,38 @@ def test_dpmpp_known_answers():
     s.lower_order_nums = 2
     c = s.step_coeffs(19)
     assert c[4] is None and float(c[2]) == 0.0 and float(c[3]) == -1.0
+
+
+def test_pndm_known_answers():
+    """"PNDM" restated (oracle/diffusers_restated.py; parity unpinned): (1) the schedule — 59 evaluations for 50 steps, the first 12 a
+    classical Runge-Kutta pattern t, t - h/2, t - h/2, t - h over three intervals of h = 20; (2) the PNDM transfer formula
+    (`_get_prev_sample`) with an exact v-prediction IS the DDIM step sqrt(a_prev) x0 + sqrt(1 - a_prev) eps (independent float64
+    evaluation), also onto final alpha 1; (3) a constant model output comes out of the Runge-Kutta combination (1/6 + 1/3 + 1/3 + 1/6)
+    and of the multistep combination ((55 - 59 + 37 - 9) / 24) unchanged."""
+    s = dr.PNDMScheduler()
+    s.set_timesteps(50)
+    ts = s.timesteps.tolist()
+    assert len(ts) == 59 and ts[:12] == [999, 989, 989, 979, 979, 969, 969, 959, 959, 949, 949, 939] and ts[12:15] == [939, 919, 899] and ts[-1] == 19
+    p = Prec("fp32")
+    g = torch.Generator().manual_seed(3)
+    x0, eps = torch.randn(5, 6, generator=g).double(), torch.randn(5, 6, generator=g).double()
+    for t, prev in ((999, 979), (519, 499), (19, -1), (999, 989)):
+        a = s.alphas_cumprod[t].double()
+        ap = (s.alphas_cumprod[prev] if prev >= 0 else s.final_alpha_cumprod).double()
+        x, v = a.sqrt() * x0 + (1 - a).sqrt() * eps, a.sqrt() * eps - (1 - a).sqrt() * x0
+        got = s._get_prev_sample(p, x.float(), t, prev, v.float()).double()
+        torch.testing.assert_close(got, ap.sqrt() * x0 + (1 - ap).sqrt() * eps, rtol=1e-5, atol=1e-5)
+    # constant model output through one Runge-Kutta group and one multistep update
+    s.set_timesteps(50)
+    x = torch.randn(5, 6, generator=g)
+    v = torch.randn(5, 6, generator=g)
+    outs = [s.step(p, v, t, x) for t in ts[:4]]
+    want = s._get_prev_sample(p, x, 999, 979, v)
+    torch.testing.assert_close(outs[3], want, rtol=1e-6, atol=1e-6)             # the 4th evaluation lands where a single step with v would
+    torch.testing.assert_close(outs[0], s._get_prev_sample(p, x, 999, 989, v), rtol=0, atol=0)
+    for t in ts[4:12]:
+        s.step(p, v, t, x)
+    assert len(s.ets) == 3 and s.counter == 12
+    y = s.step(p, v, ts[12], x)
+    torch.testing.assert_close(y, s._get_prev_sample(p, x, 939, 919, v), rtol=1e-6, atol=1e-6)
+    assert len(s.ets) == 4

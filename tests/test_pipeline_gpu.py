@@ -234,7 +234,7 @@ def test_pipeline_strength_below_one_matches_oracle(setup):
         pipe(**dict(kw, eta=0.5))
 
 
-@pytest.mark.parametrize("name", ["Euler", "Euler A", "DPM++"])
+@pytest.mark.parametrize("name", ["Euler", "Euler A", "DPM++", "PNDM"])
 def test_pipeline_other_samplers_match_oracle(setup, name):
     """The reference's sampler table beyond DDIM (demo.py:647-657): `TrajCrafter_Pipeline` with the "Euler" / "Euler A" / "DPM++"
     scheduler, 4 CFG steps from `latents=` (scaled by init_noise_sigma = sigma_max for the Euler pair, :440-446; model input through
@@ -247,7 +247,8 @@ def test_pipeline_other_samplers_match_oracle(setup, name):
     s, tp = setup, setup["tp"]
     dev = s["dev"]
     pc, oc = {"Euler": (S.EulerDiscreteScheduler, dr.EulerDiscreteScheduler), "Euler A": (S.EulerAncestralDiscreteScheduler,
-              dr.EulerAncestralDiscreteScheduler), "DPM++": (S.DPMSolverMultistepScheduler, dr.DPMSolverMultistepScheduler)}[name]
+              dr.EulerAncestralDiscreteScheduler), "DPM++": (S.DPMSolverMultistepScheduler, dr.DPMSolverMultistepScheduler),
+              "PNDM": (S.PNDMScheduler, dr.PNDMScheduler)}[name]                      # PNDM: 4 steps = 13 model evaluations
     pipe = TrajCrafter_Pipeline(None, None, s["pipe"].vae, s["pipe"].transformer, pc())
     kw = dict(prompt=None, height=32, width=48, num_frames=9, num_inference_steps=4, guidance_scale=6.0,
               prompt_embeds=tp["prompt_embeds"].to(BF), negative_prompt_embeds=tp["negative_prompt_embeds"].to(BF),
@@ -266,6 +267,10 @@ def test_pipeline_other_samplers_match_oracle(setup, name):
     ddim = s["pipe"](output_type="latent", **kw).videos
     assert not torch.equal(lat, ddim)
     assert torch.equal(pipe(output_type="latent", generator=torch.Generator(device=dev).manual_seed(21), **kw).videos, lat)
+    if name == "PNDM":               # a shortened PNDM schedule would start inside the Runge-Kutta phase: the stateful schedule refuses it
+        with pytest.raises(ValueError, match="expects timestep"):
+            pipe(**dict({k: v for k, v in kw.items() if k != "latents"}, strength=0.5, video=tp["video"]))
+        return
     # strength < 1 with this sampler: the last 2 of 4 steps from the noised video latents (scheduler.add_noise in the latent dtype)
     skw = dict({k: v for k, v in kw.items() if k != "latents"}, strength=0.5, video=tp["video"])
     g = lambda: torch.Generator(device=dev).manual_seed(43)

@@ -18,6 +18,7 @@ TCX_ATTN_BOUND_PROVEN = 2
 TCX_ATTN_BODY_16X16X32 = 4
 TCX_ATTN_BODY_4WAVE = 8
 TCX_STEP_EULER, TCX_STEP_DPMPP_2M = 0, 1
+TCX_PNDM_PRK_FIRST, TCX_PNDM_PRK_MID, TCX_PNDM_PRK_LAST, TCX_PNDM_PLMS4 = 0, 1, 2, 3
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -41,6 +42,7 @@ SIGNATURES = {
     "tcx_cfg_ddim_cog_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp],
     "tcx_cfg_sigma_step": [_vp, _vp, _vp, _vp, _i64, _f32, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
     "tcx_div_bf16": [_vp, _vp, _i64, _f32, _vp],
+    "tcx_cfg_pndm_step": [_vp, _vp, _vp, _vp, _i64, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "tcx_conv3d_cl": [_vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 16 + [_vp, _vp],
     "tcx_conv3d_route": [_i32] * 14,
     "tcx_avgpool_t": [_vp, _vp, _i32, _i32, _i64, _i32, _vp],

@@ -249,6 +249,45 @@ __global__ __launch_bounds__(256) void cfg_sigma_step_kernel(const void* u, cons
     }
 }
 
+// PNDM (diffusers PNDMScheduler, v-prediction, Runge-Kutta warm-up + 4th-order linear multistep).  mo = guided model output (fp32).
+//   MODE 0 / 1 (Runge-Kutta evaluation 1 / 2-3 of a group): cur_out = cur_in + w mo (w = 1/6, 1/3; cur_in null = the integer 0 the
+//            library starts from: 0 + w mo);  eff = mo;  MODE 0 also stores mo to `mo_out` (it joins the multistep history)
+//   MODE 2 (evaluation 4): eff = cur_in + w mo (w = 1/6)
+//   MODE 3 (multistep): eff = (1/24) (((55 mo - 59 e1) + 37 e2) - 9 e3);  mo stored to `mo_out`
+//   then  eps = sa eff + bf16r(sb x);  prev = bf16r(sc x) - (diff eps) / denom   (x = the bf16 sample `_get_prev_sample` is given)
+template <bool PRED_F32>
+__global__ __launch_bounds__(256) void cfg_pndm_step_kernel(const void* u, const void* c, const uint16_t* x, uint16_t* out, int64_t n,
+                                                            float g, int mode, float w, float sa, float sb, float sc, float diff,
+                                                            float denom, const float* e1, const float* e2, const float* e3,
+                                                            const float* cur_in, float* cur_out, float* mo_out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float uu, cc = 0.f;
+        if constexpr (PRED_F32) {
+            uu = reinterpret_cast<const float*>(u)[i];
+            if (c) cc = reinterpret_cast<const float*>(c)[i];
+        } else {
+            uu = bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(u)[i]);
+            if (c) cc = bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(c)[i]);
+        }
+        const float mo = c ? uu + g * (cc - uu) : uu;
+        float eff = mo;
+        if (mode <= 1) {
+            const float t = w * mo;
+            cur_out[i] = cur_in ? cur_in[i] + t : 0.f + t;
+            if (mode == 0) mo_out[i] = mo;
+        } else if (mode == 2) {
+            eff = cur_in[i] + w * mo;
+        } else {
+            mo_out[i] = mo;
+            eff = (1.0f / 24.0f) * (((55.0f * mo - 59.0f * e1[i]) + 37.0f * e2[i]) - 9.0f * e3[i]);
+        }
+        const float xs = bf16_bits_to_f32(x[i]);
+        const float eps = sa * eff + round_bf16(sb * xs);
+        const float prev = round_bf16(sc * xs) - (diff * eps) / denom;
+        out[i] = (uint16_t)(pack_bf16(prev, 0.f) & 0xffff);
+    }
+}
+
 // y = bf16(x / d): `scale_model_input` of the Euler samplers (a bf16 tensor divided by a 0-dim fp32 tensor stays bf16)
 __global__ __launch_bounds__(256) void div_kernel(const uint16_t* x, uint16_t* y, int64_t n, float d) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -502,6 +541,30 @@ extern "C" int tcx_cfg_sigma_step(const void* u, const void* c, const void* x, v
         else
             hipLaunchKernelGGL((cfg_sigma_step_kernel<false, 1>), grid, dim3(256), 0, st, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, k0, k1, k2, k3, k4, hist_in, hist_out, nullptr);
     }
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_cfg_pndm_step(const void* u, const void* c, const void* x, void* out, int64_t n, float guidance, int32_t mode,
+                                 const float* coef, const float* e1, const float* e2, const float* e3, const float* cur_in,
+                                 float* cur_out, float* mo_out, int32_t pred_dtype, void* stream) {
+    TCX_CHECK(u && x && out && coef, TCX_E_NULL, "tcx_cfg_pndm_step: null pointer");
+    TCX_CHECK(n > 0, TCX_E_SHAPE, "tcx_cfg_pndm_step: n must be positive");
+    TCX_CHECK(pred_dtype == TCX_BF16 || pred_dtype == TCX_F32, TCX_E_DTYPE, "tcx_cfg_pndm_step: bad pred_dtype %d", pred_dtype);
+    TCX_CHECK(mode >= TCX_PNDM_PRK_FIRST && mode <= TCX_PNDM_PLMS4, TCX_E_SHAPE, "tcx_cfg_pndm_step: unknown mode %d", mode);
+    for (int j = 0; j < 6; ++j) TCX_CHECK(coef[j] == coef[j], TCX_E_SHAPE, "tcx_cfg_pndm_step: coef[%d] is NaN", j);
+    TCX_CHECK(coef[5] != 0.f, TCX_E_SHAPE, "tcx_cfg_pndm_step: the denominator (coef[5]) is zero");
+    if (mode == TCX_PNDM_PRK_FIRST) TCX_CHECK(cur_out && mo_out, TCX_E_NULL, "tcx_cfg_pndm_step: first Runge-Kutta evaluation needs cur_out and mo_out");
+    if (mode == TCX_PNDM_PRK_MID) TCX_CHECK(cur_in && cur_out, TCX_E_NULL, "tcx_cfg_pndm_step: middle Runge-Kutta evaluations need cur_in and cur_out");
+    if (mode == TCX_PNDM_PRK_LAST) TCX_CHECK(cur_in != nullptr, TCX_E_NULL, "tcx_cfg_pndm_step: last Runge-Kutta evaluation needs cur_in");
+    if (mode == TCX_PNDM_PLMS4) TCX_CHECK(e1 && e2 && e3 && mo_out, TCX_E_NULL, "tcx_cfg_pndm_step: the multistep update needs e1..e3 and mo_out");
+    TCX_CHECK(mo_out == nullptr || (mo_out != e1 && mo_out != e2 && mo_out != e3), TCX_E_SHAPE, "tcx_cfg_pndm_step: mo_out must not alias the history");
+    hipStream_t st = (hipStream_t)stream;
+    if (pred_dtype == TCX_F32)
+        hipLaunchKernelGGL(cfg_pndm_step_kernel<true>, dim3(grid_for(n)), dim3(256), 0, st, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, mode,
+                           coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], e1, e2, e3, cur_in, cur_out, mo_out);
+    else
+        hipLaunchKernelGGL(cfg_pndm_step_kernel<false>, dim3(grid_for(n)), dim3(256), 0, st, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, mode,
+                           coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], e1, e2, e3, cur_in, cur_out, mo_out);
     TCX_LAUNCH_RET();
 }
 

@@ -128,7 +128,8 @@ class TrajCrafter_Pipeline:
             raise NotImplementedError(
                 f"scheduler {type(self.scheduler).__name__} is not built on this path: the denoise loop fuses CFG + step into one "
                 "kernel per scheduler class; built (trajectorycrafter_amd.scheduler): DDIMScheduler ('DDIM_Origin'), CogVideoXDDIMScheduler "
-                "('DDIM_Cog'), EulerDiscreteScheduler ('Euler'), EulerAncestralDiscreteScheduler ('Euler A'), DPMSolverMultistepScheduler ('DPM++')")
+                "('DDIM_Cog'), EulerDiscreteScheduler ('Euler'), EulerAncestralDiscreteScheduler ('Euler A'), DPMSolverMultistepScheduler ('DPM++'), "
+                "PNDMScheduler ('PNDM')")
         self.vae_scale_factor_spatial = 2 ** (len(self.vae.config.block_out_channels) - 1) if vae is not None else 8
         self.vae_scale_factor_temporal = int(self.vae.config.temporal_compression_ratio) if vae is not None else 4
         self.vae_scale_factor = self.vae_scale_factor_spatial

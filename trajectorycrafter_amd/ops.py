@@ -316,6 +316,35 @@ def cfg_sigma_step(kind: int, uncond: torch.Tensor, cond: Optional[torch.Tensor]
     return out
 
 
+def cfg_pndm_step(mode: int, uncond: torch.Tensor, cond: Optional[torch.Tensor], x: torch.Tensor, guidance: float, coef,
+                  e1: Optional[torch.Tensor] = None, e2: Optional[torch.Tensor] = None, e3: Optional[torch.Tensor] = None,
+                  cur_in: Optional[torch.Tensor] = None, cur_out: Optional[torch.Tensor] = None,
+                  mo_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """CFG + one `PNDMScheduler.step` (Runge-Kutta evaluation or 4th-order multistep update), fused (`tcx_cfg_pndm_step`); `coef`:
+    the 6 fp32 scalars of include/tcx_hip.h; history / accumulator tensors fp32 of the latents' size."""
+    import ctypes
+    _need(x, "x")
+    if uncond.dtype not in (BF16, torch.float32):
+        raise TcxError(f"cfg_pndm_step: prediction dtype {uncond.dtype} unsupported")
+    if not (uncond.is_contiguous() and x.is_contiguous() and (cond is None or cond.is_contiguous())):
+        raise TcxError("cfg_pndm_step: tensors must be contiguous")
+    if uncond.numel() != x.numel() or (cond is not None and (cond.numel() != x.numel() or cond.dtype != uncond.dtype)):
+        raise TcxError("cfg_pndm_step: size / dtype mismatch")
+    for name, t in (("e1", e1), ("e2", e2), ("e3", e3), ("cur_in", cur_in), ("cur_out", cur_out), ("mo_out", mo_out)):
+        if t is not None:
+            _need(t, name, torch.float32)
+            if not t.is_contiguous() or t.numel() != x.numel():
+                raise TcxError(f"cfg_pndm_step: {name} must be a contiguous fp32 tensor of the latents' size")
+    if len(coef) != 6:
+        raise TcxError("cfg_pndm_step: coef holds 6 scalars")
+    carr = (ctypes.c_float * 6)(*[float(v) for v in coef])
+    out = torch.empty_like(x)
+    check(_lib.load().tcx_cfg_pndm_step(_p(uncond), _p(cond), _p(x), _p(out), x.numel(), float(guidance), int(mode),
+                                        ctypes.cast(carr, ctypes.c_void_p), _p(e1), _p(e2), _p(e3), _p(cur_in), _p(cur_out), _p(mo_out),
+                                        TCX_F32 if uncond.dtype == torch.float32 else TCX_BF16, _stream()), "tcx_cfg_pndm_step")
+    return out
+
+
 def div_bf16(x: torch.Tensor, d: float) -> torch.Tensor:
     """bf16(x / d) (`tcx_div_bf16`): the Euler samplers' `scale_model_input`."""
     _need(x, "x")

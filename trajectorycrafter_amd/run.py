@@ -27,8 +27,8 @@ from typing import Optional
 
 import torch
 
-SAMPLERS = ("DDIM_Origin", "DDIM_Cog", "Euler", "Euler A", "DPM++")      # built; the reference's table (demo.py:647-654) has one more
-_NOT_BUILT = ("PNDM",)
+SAMPLERS = ("DDIM_Origin", "DDIM_Cog", "Euler", "Euler A", "DPM++", "PNDM")      # the reference's whole table (demo.py:647-654)
+_NOT_BUILT = ()
 
 
 def make_scheduler(sampler_name: str, model_dir: Optional[str]):
@@ -40,7 +40,7 @@ def make_scheduler(sampler_name: str, model_dir: Optional[str]):
     if sampler_name not in SAMPLERS:
         raise ValueError(f"unknown sampler {sampler_name!r}; the reference's choices: {SAMPLERS + _NOT_BUILT}")
     cls = {"DDIM_Origin": S.DDIMScheduler, "DDIM_Cog": S.CogVideoXDDIMScheduler, "Euler": S.EulerDiscreteScheduler,
-           "Euler A": S.EulerAncestralDiscreteScheduler, "DPM++": S.DPMSolverMultistepScheduler}[sampler_name]
+           "Euler A": S.EulerAncestralDiscreteScheduler, "DPM++": S.DPMSolverMultistepScheduler, "PNDM": S.PNDMScheduler}[sampler_name]
     if model_dir and os.path.exists(os.path.join(model_dir, "scheduler", "scheduler_config.json")):
         return cls.from_pretrained(model_dir, subfolder="scheduler")
     return cls()

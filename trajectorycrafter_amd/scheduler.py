@@ -323,3 +323,123 @@ class DPMSolverMultistepScheduler(_SigmaSampler):
         if self._lower_order_nums < self.solver_order:
             self._lower_order_nums += 1
         return out
+
+
+class PNDMScheduler:
+    """ "PNDM" (demo.py:651): diffusers `PNDMScheduler` as `from_pretrained` builds it from the CogVideoX scheduler config — scaled-linear
+    betas WITHOUT the zero-terminal-SNR rescale (the class has no such option and ignores the key), v_prediction, trailing spacing,
+    set_alpha_to_one, skip_prk_steps = False: `set_timesteps(50)` yields 59 timesteps (12 Runge-Kutta evaluations over the first three
+    intervals, then 47 fourth-order multistep updates) and the pipeline loops over all of them.  Restated from the published algorithm
+    (parity unpinned).  Host: the fp32 alpha table, the evaluation counter and which history tensors exist; device: one fused kernel
+    per step (`tcx_cfg_pndm_step`) + four fp32 history tensors and one accumulator of the latents' size."""
+    order = 1
+    init_noise_sigma = 1.0
+    pndm_order = 4
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
+                 beta_schedule: str = "scaled_linear", prediction_type: str = "v_prediction", timestep_spacing: str = "trailing",
+                 set_alpha_to_one: bool = True, steps_offset: int = 0, skip_prk_steps: bool = False, **unused):
+        if beta_schedule != "scaled_linear":
+            raise ValueError(f"beta_schedule {beta_schedule!r} not supported")
+        if prediction_type != "v_prediction":
+            raise ValueError("the fused HIP step implements v_prediction (CogVideoX); got " + prediction_type)
+        if skip_prk_steps:
+            raise ValueError("skip_prk_steps=True is not built (the library's default, and what the reference's table gets, is False)")
+        if timestep_spacing not in ("trailing", "leading"):
+            raise ValueError(f"timestep_spacing {timestep_spacing!r} not supported")
+        self.config = FrozenConfig(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                   beta_schedule=beta_schedule, prediction_type=prediction_type, timestep_spacing=timestep_spacing,
+                                   set_alpha_to_one=set_alpha_to_one, steps_offset=steps_offset, skip_prk_steps=skip_prk_steps)
+        self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.timesteps: Optional[torch.Tensor] = None
+        self.num_inference_steps: Optional[int] = None
+
+    from_pretrained = classmethod(DDIMScheduler.from_pretrained.__func__)
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        N, n = self.config.num_train_timesteps, num_inference_steps
+        if n > N:
+            raise ValueError(f"num_inference_steps ({n}) > num_train_timesteps ({N})")
+        if n < self.pndm_order:
+            raise ValueError(f"PNDM with Runge-Kutta warm-up needs at least {self.pndm_order} inference steps, got {n}")
+        self.num_inference_steps = n
+        if self.config.timestep_spacing == "trailing":
+            grid = np.round(np.arange(N, 0, -N / n))[::-1].astype(np.int64) - 1
+        else:
+            grid = (np.arange(0, n) * (N // n)).round().astype(np.int64) + self.config.steps_offset
+        half = N // n // 2
+        prk = np.array(grid[-self.pndm_order:]).repeat(2) + np.tile(np.array([0, half]), self.pndm_order)
+        self.prk_timesteps = (prk[:-1].repeat(2)[1:-1])[::-1].copy()
+        self.plms_timesteps = grid[:-3][::-1].copy()
+        self.timesteps = torch.from_numpy(np.concatenate([self.prk_timesteps, self.plms_timesteps]).astype(np.int64))
+        self._counter = 0
+        self._ets: list = []                 # newest last, at most 4 fp32 tensors (rotated, never reallocated after the fourth)
+        self._cur = None                     # Runge-Kutta running sum (fp32)
+        self._cur_sample = None              # the sample a Runge-Kutta group started from
+
+    def scale_model_input(self, sample: torch.Tensor, timestep=None) -> torch.Tensor:
+        return sample
+
+    def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timesteps) -> torch.Tensor:
+        """The library's `add_noise`: sqrt(a_t) x0 + sqrt(1 - a_t) noise with the table cast to the sample dtype (as DDIMScheduler's)."""
+        return DDIMScheduler.add_noise(self, original_samples, noise, timesteps)
+
+    def prev_coeffs(self, timestep: int, prev_timestep: int):
+        """[sqrt(a_t), sqrt(1 - a_t), sqrt(a_prev / a_t), a_prev - a_t, a_t sqrt(1 - a_prev) + sqrt(a_t (1 - a_t) a_prev)]: the library's
+        expressions of `_get_prev_sample` on 0-dim fp32 tensors."""
+        a = self.alphas_cumprod[timestep]
+        ap = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b, bp = 1 - a, 1 - ap
+        return [float(a ** 0.5), float(b ** 0.5), float((ap / a) ** 0.5), float(ap - a), float(a * bp ** 0.5 + (a * b * ap) ** 0.5)]
+
+    def _buf(self, like: torch.Tensor) -> torch.Tensor:
+        return torch.empty(like.shape, device=like.device, dtype=torch.float32)
+
+    def fused_cfg_step(self, uncond, cond, sample, guidance: float, timestep, generator=None) -> torch.Tensor:
+        from . import _lib, ops
+        if self.timesteps is None:
+            raise RuntimeError("call set_timesteps first")
+        N, n = self.config.num_train_timesteps, self.num_inference_steps
+        t = int(timestep)
+        if self._counter >= len(self.timesteps):
+            raise RuntimeError("PNDM: more steps than set_timesteps scheduled (the schedule is stateful: call set_timesteps again)")
+        if t != int(self.timesteps[self._counter]):
+            raise ValueError(f"PNDM: step {self._counter} expects timestep {int(self.timesteps[self._counter])}, got {t} "
+                             "(the schedule is stateful: steps must follow `timesteps` in order)")
+        if self._counter < len(self.prk_timesteps):                      # a Runge-Kutta evaluation (library: step_prk)
+            k = self._counter % 4
+            prev_t = t - (0 if self._counter % 2 else N // n // 2)
+            group_t = int(self.prk_timesteps[self._counter // 4 * 4])
+            coef = self.prev_coeffs(group_t, prev_t)
+            if k == 0:
+                self._cur_sample = sample
+                self._cur = self._buf(sample)
+                mo = self._buf(sample)
+                out = ops.cfg_pndm_step(_lib.TCX_PNDM_PRK_FIRST, uncond, cond, self._cur_sample, guidance, [1 / 6] + coef,
+                                        cur_out=self._cur, mo_out=mo)
+                self._ets.append(mo)
+            elif k in (1, 2):
+                nxt = self._buf(sample)
+                out = ops.cfg_pndm_step(_lib.TCX_PNDM_PRK_MID, uncond, cond, self._cur_sample, guidance, [1 / 3] + coef,
+                                        cur_in=self._cur, cur_out=nxt)
+                self._cur = nxt
+            else:
+                out = ops.cfg_pndm_step(_lib.TCX_PNDM_PRK_LAST, uncond, cond, self._cur_sample, guidance, [1 / 6] + coef, cur_in=self._cur)
+                self._cur = None
+        else:                                                            # 4th-order linear multistep (library: step_plms)
+            if len(self._ets) < 3:
+                raise RuntimeError("PNDM: the multistep phase needs the three Runge-Kutta outputs first")
+            coef = self.prev_coeffs(t, t - N // n)
+            hist = self._ets[-3:]
+            mo = self._ets[0] if len(self._ets) == 4 else self._buf(sample)   # recycle the oldest tensor once four exist
+            out = ops.cfg_pndm_step(_lib.TCX_PNDM_PLMS4, uncond, cond, sample, guidance, [1 / 24] + coef,
+                                    e1=hist[-1], e2=hist[-2], e3=hist[-3], mo_out=mo)
+            self._ets = hist + [mo]
+        self._counter += 1
+        return out
+
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, return_dict: bool = False, **kw):
+        """diffusers-shaped step (no guidance) on the fused kernel."""
+        return (self.fused_cfg_step(model_output.contiguous(), None, sample.contiguous(), 1.0, timestep),)
