@@ -347,6 +347,14 @@ int tcx_warp_forward(const float* frame, const float* mask1, const float* depth,
                      float* flow, float* tdepth, float* acc, float* warped, float* mask2, float* wdepth,
                      int32_t b, int32_t h, int32_t w, int32_t flags, void* stream);
 
+/* One `Warper.bilinear_splatting(frame1, mask1, depth1, flow12, None, is_image)` of the reference (models/utils.py:422-583) on its
+ * own: src [b,c,h,w] fp32 with 1 <= c <= 4, mask1 [b,1,h,w] or null, depth [b,h,w] (the weights exp(50 log(1+d) / max log(1+d)), max
+ * over the whole batch like the reference), flow [b,2,h,w] multiplied by `flow_scale` (-1 for the reverse splat) -> out [b,c,h,w]
+ * (is_image: holes = -1 and the result clamped to [-1, 1]; else holes = 0) and mask2 [b,1,h,w].  acc: scratch of
+ * b (h+2)(w+2) 5 + 1 floats.  The building block of forward_warp(twice=True) (:294-347), whose first stage is tcx_warp_forward. */
+int tcx_bilinear_splat(const float* src, const float* mask1, const float* depth, const float* flow, float* acc, float* out,
+                       float* mask2, int32_t b, int32_t c, int32_t h, int32_t w, int32_t is_image, float flow_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

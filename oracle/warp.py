@@ -92,3 +92,21 @@ def forward_warp(frame1, mask1, depth1, t1, t2, k1, k2=None, mask=False):
     if mask:
         warped, mask2 = clean_points(warped, mask2)
     return warped, mask2, wdepth, flow
+
+
+def forward_warp_twice(frame1, mask1, depth1, t1, t2, k1, k2=None):
+    """reference :294-347 (`twice=True`, mask=False): the first warp, the flow splatted like an image, then frame and depth splatted
+    back along the negated warped flow with the warped depth as weight -> (twice_warped_frame1, twice_warped_mask1,
+    twice_warped_depth1, None)."""
+    pts = transformed_points(depth1, t1, t2, k1, k2)
+    coords = pts[..., :2] / pts[..., 2:3]
+    tdepth = pts[..., 2]
+    b, _, h, w = frame1.shape
+    ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    flow = coords.permute(0, 3, 1, 2) - torch.stack([xs, ys], 0)[None].to(coords)
+    warped2, mask2 = bilinear_splat(frame1, mask1, tdepth, flow, True)
+    wdepth2, _ = bilinear_splat(tdepth[:, None], mask1, tdepth, flow, False)
+    warped_flow, _ = bilinear_splat(flow, mask1, tdepth, flow, False)
+    tw_frame, tw_mask = bilinear_splat(warped2, mask2, wdepth2[:, 0], -warped_flow, True)
+    tw_depth, _ = bilinear_splat(wdepth2, mask2, wdepth2[:, 0], -warped_flow, False)
+    return tw_frame, tw_mask, tw_depth, None

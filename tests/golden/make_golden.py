@@ -451,10 +451,14 @@ def make_warp():
         t2[n, :3, 3] = torch.tensor([tx, 0.05, -tz])
     with torch.no_grad():
         warped, mask2, wdepth, flow = Warper(device="cpu").forward_warp(frame, None, depth, t1, t2, k, None, False, twice=False)
+        tw_frame, tw_mask, tw_depth, tw_none = Warper(device="cpu").forward_warp(frame, None, depth, t1, t2, k, None, False, twice=True)
+    assert tw_none is None
     save("warp_tiny.safetensors",
          dict(frame=frame, depth=depth, t1=t1, t2=t2, K=k, warped=warped.float(), mask2=mask2.float(),
-              warped_depth=wdepth.float(), flow=flow.float()),
-         dict(source="reference models/utils.py Warper.forward_warp(frame, None, depth, t1, t2, K, None, False, twice=False)", seed=4242))
+              warped_depth=wdepth.float(), flow=flow.float(), twice_frame=tw_frame.float(), twice_mask=tw_mask.float(),
+              twice_depth=tw_depth.float()),
+         dict(source="reference models/utils.py Warper.forward_warp(frame, None, depth, t1, t2, K, None, False, twice=False) and (..., twice=True)",
+              seed=4242))
 
 
 def _stub_utils_imports():

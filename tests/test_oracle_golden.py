@@ -127,3 +127,9 @@ def test_forward_warp_matches_reference(golden):
     _close(warped, t["warped"], rtol=2e-5, atol=5e-5)
     _close(wdepth, t["warped_depth"], rtol=2e-5, atol=5e-5)
     assert 0.1 < float(mask2[1].mean()) < 0.3 and float(mask2[0].mean()) > 0.7     # the fixture has holes and occlusion
+    # twice=True (reference :294-347): warp there, splat the flow, splat frame and depth back along the negated warped flow
+    tw_frame, tw_mask, tw_depth, none = warp.forward_warp_twice(t["frame"], None, t["depth"], t["t1"], t["t2"], t["K"])
+    assert none is None and torch.equal(tw_mask, t["twice_mask"])
+    _close(tw_frame, t["twice_frame"], rtol=2e-5, atol=5e-5)
+    _close(tw_depth, t["twice_depth"], rtol=2e-5, atol=5e-5)
+    assert 0.5 < float(tw_mask[0].mean()) < 1.0                                      # back in the source view, with the occlusions as holes

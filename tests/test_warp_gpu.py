@@ -70,6 +70,56 @@ def test_forward_warp_matches_oracle(warper, b, h, w, with_mask):
     _cmp(got, want, 1e-3 if h * w > 1 else 0.0)
 
 
+def test_forward_warp_twice_matches_reference_fixture_and_oracle(warper, golden):
+    """forward_warp(twice=True) (reference :294-347; its caller is notebooks/15_10_25_depth/collect_dataset.py): the fused first
+    stage + three `tcx_bilinear_splat` launches against the reference's own output (fixture) and the oracle on a larger scene with a
+    source mask.  Every stage re-splats the previous stage's output, so its ill-conditioned pixels compound: the shares of
+    test_forward_warp_matches_oracle are allowed twice over."""
+    t, _ = golden("warp_tiny.safetensors")
+    f, m, d, none = warper.forward_warp(t["frame"], None, t["depth"], t["t1"], t["t2"], t["K"], None, False, twice=True)
+    assert none is None and f.shape == t["twice_frame"].shape
+    mdiff = (m.cpu() != t["twice_mask"])
+    assert float(mdiff.float().mean()) <= 2e-3
+    same = ~mdiff
+    for a, e in ((f.cpu()[same.expand_as(f)], t["twice_frame"][same.expand_as(f)]), (d.cpu()[same], t["twice_depth"][same])):
+        err = (a - e).abs()
+        assert float((err > 1e-4 + 5e-5 * e.abs()).float().mean()) <= 2e-3 and float((err / (1 + e.abs())).max()) <= 4e-2
+    frame, mask1, depth, t1, t2, k = _scene(2, 48, 80, 77, True)
+    want = owarp.forward_warp_twice(frame, mask1, depth, t1, t2, k)
+    got = warper.forward_warp(frame, mask1, depth, t1, t2, k, None, False, twice=True)
+    mdiff = got[1].cpu() != want[1]
+    assert float(mdiff.float().mean()) <= 4e-3
+    same = ~mdiff
+    for a, e in ((got[0].cpu()[same.expand_as(want[0])], want[0][same.expand_as(want[0])]), (got[2].cpu()[same], want[2][same])):
+        err = (a - e).abs()
+        assert float((err > 1e-4 + 5e-5 * e.abs()).float().mean()) <= 1e-2, float((err > 1e-4 + 5e-5 * e.abs()).float().mean())
+        assert float(torch.quantile(err / (1 + e.abs()), 0.999)) <= 4e-2
+    with pytest.raises(NotImplementedError, match="mask=False"):
+        warper.forward_warp(frame, mask1, depth, t1, t2, k, None, True, twice=True)
+
+
+@pytest.mark.parametrize("c,is_image,with_mask,scale", [(3, True, False, 1.0), (1, False, True, -1.0), (2, False, False, 1.0), (4, True, True, -1.0)])
+def test_bilinear_splat_matches_oracle(c, is_image, with_mask, scale):
+    """`tcx_bilinear_splat` = one `Warper.bilinear_splatting` (reference :422-583) with a given flow: 1..4 channels, image / non-image
+    hole value and clamp, optional source mask, the negated flow of the return splat."""
+    from trajectorycrafter_amd import ops
+    g = torch.Generator().manual_seed(10 * c + int(is_image))
+    b, h, w = 2, 40, 56
+    src = torch.rand(b, c, h, w, generator=g) * 2 - 1
+    depth = 0.5 + 3 * torch.rand(b, h, w, generator=g)
+    flow = (torch.rand(b, 2, h, w, generator=g) - 0.5) * 9
+    mask1 = (torch.rand(b, 1, h, w, generator=g) > 0.2).float() if with_mask else None
+    want, wmask = owarp.bilinear_splat(src, mask1, depth, flow * scale, is_image)
+    got, gmask = ops.bilinear_splat(src.cuda(), None if mask1 is None else mask1.cuda(), depth.cuda(), flow.cuda(), is_image, flow_scale=scale)
+    mdiff = gmask.cpu() != wmask
+    assert float(mdiff.float().mean()) <= 1e-3
+    same = (~mdiff).expand_as(want)
+    err = (got.cpu()[same] - want[same]).abs()
+    assert float((err > 1e-4 + 5e-5 * want[same].abs()).float().mean()) <= 2e-3 and float(err.max()) <= 5e-2
+    with pytest.raises(ops.TcxError):
+        ops.bilinear_splat(torch.zeros(1, 5, 4, 4, device="cuda"), None, torch.ones(1, 4, 4, device="cuda"), torch.zeros(1, 2, 4, 4, device="cuda"), True)
+
+
 def test_forward_warp_mask_true_cleans_points(warper):
     """forward_warp(mask=True): holes dilated 5x5 inside the resolve kernel (reference clean_points :585-626)."""
     frame, _, depth, t1, t2, k = _scene(1, 60, 90, 21, False)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "tcx_scale_sqmax_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _f32, _vp, _vp],
     "tcx_gemm_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp],
     "tcx_warp_forward": [_vp] * 10 + [_i32, _i32, _i32, _i32, _vp],
+    "tcx_bilinear_splat": [_vp] * 7 + [_i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "tcx_groupnorm_stats": [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _i32, _vp],
     "tcx_groupnorm_spatialnorm_silu": [_vp] * 7 + [_i32] * 9 + [_vp, _i32, _vp],
     "tcx_ncthw_to_cl": [_vp, _vp, _i32, _i32, _i64, _f32, _vp],

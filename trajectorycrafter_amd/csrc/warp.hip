@@ -177,6 +177,78 @@ __global__ __launch_bounds__(256) void warp_resolve_kernel(const WarpParams p) {
     }
 }
 
+// ---- generic bilinear splat: Warper.bilinear_splatting (reference models/utils.py:422-583) of an arbitrary C <= 4 channel image
+// along a GIVEN flow with depth weights from a GIVEN depth map — the building block of forward_warp(twice=True) (:294-347), which is
+// off the inference path: plain global atomics, no LDS window.
+struct SplatParams {
+    const float *src, *mask1, *depth, *flow;
+    float *acc, *out, *mask2;
+    unsigned* logmax;
+    int32_t b, c, h, w, is_image;
+    float flow_scale;
+};
+
+__global__ __launch_bounds__(256) void splat_logmax_kernel(const SplatParams p) {
+    const int64_t total = (int64_t)p.b * p.h * p.w;
+    float lmax = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        lmax = fmaxf(lmax, logf(1.0f + fminf(fmaxf(p.depth[i], 0.f), 1000.0f)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(p.logmax, __float_as_uint(lmax));
+}
+
+__global__ __launch_bounds__(256) void splat_generic_kernel(const SplatParams p) {
+    const int64_t hw = (int64_t)p.h * p.w, total = (int64_t)p.b * hw;
+    const int W2 = p.w + 2, H2 = p.h + 2;
+    const float lim_x = (float)(p.w + 1), lim_y = (float)(p.h + 1);
+    const float logmax = __uint_as_float(*p.logmax);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / hw);
+        const int64_t pix = i - (int64_t)n * hw;
+        const int x = (int)(pix % p.w), y = (int)(pix / p.w);
+        float px = p.flow[(2 * (int64_t)n) * hw + pix] * p.flow_scale + (float)x + 1.0f;
+        float py = p.flow[(2 * (int64_t)n + 1) * hw + pix] * p.flow_scale + (float)y + 1.0f;
+        const float flx = fminf(fmaxf(floorf(px), 0.f), lim_x), fly = fminf(fmaxf(floorf(py), 0.f), lim_y);
+        const float cex = fminf(fmaxf(ceilf(px), 0.f), lim_x), cey = fminf(fmaxf(ceilf(py), 0.f), lim_y);
+        px = fminf(fmaxf(px, 0.f), lim_x);
+        py = fminf(fmaxf(py, 0.f), lim_y);
+        const float wx[2] = {1.0f - (px - flx), 1.0f - (cex - px)}, wy[2] = {1.0f - (py - fly), 1.0f - (cey - py)};
+        const int ix[2] = {(int)flx, (int)cex}, iy[2] = {(int)fly, (int)cey};
+        const float dw = expf(logf(1.0f + fminf(fmaxf(p.depth[i], 0.f), 1000.0f)) / logmax * 50.0f);
+        const float base = (p.mask1 ? p.mask1[i] : 1.0f) / dw;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ch = 0; ch < p.c; ++ch) v[ch] = p.src[((int64_t)n * p.c + ch) * hw + pix];
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+                const float wg = wy[cy] * wx[cx] * base;
+                float* dst = p.acc + (((int64_t)n * H2 + iy[cy]) * W2 + ix[cx]) * 5;
+                for (int ch = 0; ch < p.c; ++ch) atomicAdd(dst + ch, v[ch] * wg);
+                atomicAdd(dst + 4, wg);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void splat_resolve_kernel(const SplatParams p) {
+    const int64_t hw = (int64_t)p.h * p.w, total = (int64_t)p.b * hw;
+    const int W2 = p.w + 2, H2 = p.h + 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % p.w), y = (int)((i / p.w) % p.h), n = (int)(i / hw);
+        const int64_t pix = i - (int64_t)n * hw;
+        const float* a = p.acc + (((int64_t)n * H2 + y + 1) * W2 + x + 1) * 5;
+        const float wsum = a[4];
+        const bool hit = wsum > 0.f;
+        for (int ch = 0; ch < p.c; ++ch) {
+            float o = hit ? a[ch] / wsum : (p.is_image ? -1.0f : 0.0f);
+            if (p.is_image) o = fminf(fmaxf(o, -1.0f), 1.0f);
+            p.out[((int64_t)n * p.c + ch) * hw + pix] = o;
+        }
+        p.mask2[i] = hit ? 1.0f : 0.0f;
+    }
+}
+
 inline unsigned wgrid(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (unsigned)(b > 256 * 8 ? 256 * 8 : (b < 1 ? 1 : b));
@@ -205,5 +277,23 @@ extern "C" int tcx_warp_forward(const float* frame, const float* mask1, const fl
     hipLaunchKernelGGL(warp_project_kernel, dim3(pblocks, b), dim3(256), 0, st, p);
     hipLaunchKernelGGL(warp_splat_kernel, dim3((w + kTile - 1) / kTile, (h + kTile - 1) / kTile, b), dim3(256), 0, st, p);
     hipLaunchKernelGGL(warp_resolve_kernel, dim3(wgrid(total)), dim3(256), 0, st, p);
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_bilinear_splat(const float* src, const float* mask1, const float* depth, const float* flow, float* acc, float* out,
+                                  float* mask2, int32_t b, int32_t c, int32_t h, int32_t w, int32_t is_image, float flow_scale,
+                                  void* stream) {
+    TCX_CHECK(src && depth && flow && acc && out && mask2, TCX_E_NULL, "tcx_bilinear_splat: null pointer");
+    TCX_CHECK(b > 0 && h > 0 && w > 0 && c >= 1 && c <= 4, TCX_E_SHAPE, "tcx_bilinear_splat: need 1 <= channels <= 4 and a non-empty image");
+    TCX_CHECK((int64_t)b * h * w < (1ll << 40), TCX_E_SHAPE, "tcx_bilinear_splat: image too large");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t acc_floats = (size_t)b * (h + 2) * (w + 2) * 5 + 1;                       // + 1 word: max log-depth
+    hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * acc_floats, st);
+    if (e != hipSuccess) { tcx_set_error("tcx_bilinear_splat: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    SplatParams p{src, mask1, depth, flow, acc, out, mask2, reinterpret_cast<unsigned*>(acc + acc_floats - 1), b, c, h, w, is_image ? 1 : 0, flow_scale};
+    const int64_t total = (int64_t)b * h * w;
+    hipLaunchKernelGGL(splat_logmax_kernel, dim3(wgrid(total)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(splat_generic_kernel, dim3(wgrid(total)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(splat_resolve_kernel, dim3(wgrid(total)), dim3(256), 0, st, p);
     TCX_LAUNCH_RET();
 }

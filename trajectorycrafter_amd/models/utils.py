@@ -3,7 +3,9 @@
 Built: `forward_warp(..., mask=False|True, twice=False)` — what demo.py calls (`--mask` selects `clean_points`, the
 5x5 dilation of the holes, done here inside the resolve kernel instead of a cv2 round trip through the host; with
 mask=True the reference returns float64 because of a numpy promotion, this returns fp32).  The 4x4 / 3x3 inverses are tiny host-side
-torch ops; projection, splatting (float atomics) and normalisation are HIP kernels (`tcx_warp_forward`)."""
+torch ops; projection, splatting (float atomics) and normalisation are HIP kernels (`tcx_warp_forward`).
+`twice=True` (reference :294-347, mask=False): that fused stage, then the flow, the warped frame and the warped depth through the
+generic splat `tcx_bilinear_splat`."""
 from __future__ import annotations
 
 from typing import Optional, Tuple
@@ -27,8 +29,9 @@ class Warper:
         """reference :220-293 -> (warped_frame2 [b,3,h,w] in [-1,1], mask2 [b,1,h,w], warped_depth2 [b,1,h,w], flow12 [b,2,h,w]).
         per_frame=True (not in the reference): the b items are b independent batch-1 reference calls — the whole clip
         of demo.py:100-116's per-frame loop in one launch."""
-        if twice:
-            raise NotImplementedError("forward_warp(twice=True) is not on the reference's inference path (demo.py passes twice=False)")
+        if twice and (mask or per_frame):
+            raise NotImplementedError("forward_warp(twice=True) is built for mask=False (its only caller, notebooks/15_10_25_depth/"
+                                      "collect_dataset.py:272-282; with mask=True the reference dilates an already dilated mask, :307-343)")
         if self.device.type != "cuda":
             raise TcxError("Warper: the HIP splat needs a GPU device (no CPU fallback; use oracle.warp on the CPU)")
         if self.resolution is not None:
@@ -44,5 +47,16 @@ class Warper:
         t1, t2, k1, k2 = (t.to(**to) for t in (transformation1, transformation2, intrinsic1, intrinsic2))
         rel = torch.bmm(t2, torch.linalg.inv(t1))                                 # :365-367
         mats = torch.cat([torch.linalg.inv(k1).reshape(b, 9), rel[:, :3, :].reshape(b, 12), k2.reshape(b, 9)], dim=1).contiguous()
-        return ops.warp_forward(frame1.to(**to).contiguous(), None if mask1 is None else mask1.to(**to).contiguous(),
-                                depth1.to(**to).contiguous(), mats, per_item_max=per_frame, clean_points=bool(mask))
+        m1 = None if mask1 is None else mask1.to(**to).contiguous()
+        if not twice:
+            return ops.warp_forward(frame1.to(**to).contiguous(), m1, depth1.to(**to).contiguous(), mats, per_item_max=per_frame,
+                                    clean_points=bool(mask))
+        # reference :294-347: warp to the target view, splat the flow itself the same way, then splat frame and depth BACK along the
+        # negated warped flow with the warped depth as the weight (the target-view occlusions end up as holes in the source view)
+        warped2, mask2, wdepth2, flow12, tdepth = ops.warp_forward(frame1.to(**to).contiguous(), m1, depth1.to(**to).contiguous(), mats,
+                                                                   return_tdepth=True)
+        warped_flow, _ = ops.bilinear_splat(flow12, m1, tdepth, flow12, is_image=False)
+        d2 = wdepth2[:, 0].contiguous()
+        twice_frame1, twice_mask1 = ops.bilinear_splat(warped2, mask2, d2, warped_flow, is_image=True, flow_scale=-1.0)
+        twice_depth1, _ = ops.bilinear_splat(wdepth2, mask2, d2, warped_flow, is_image=False, flow_scale=-1.0)
+        return twice_frame1, twice_mask1, twice_depth1, None

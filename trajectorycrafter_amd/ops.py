@@ -567,8 +567,27 @@ def cl_to_frames(x: torch.Tensor, out: torch.Tensor, t_offset: int) -> None:
 
 
 # ----------------------------------------------------------------------------- point-cloud render
+def bilinear_splat(src: torch.Tensor, mask1: Optional[torch.Tensor], depth: torch.Tensor, flow: torch.Tensor, is_image: bool,
+                   flow_scale: float = 1.0):
+    """`Warper.bilinear_splatting` (reference models/utils.py:422-583): src [b,c<=4,h,w], mask1 [b,1,h,w] | None, depth [b,h,w],
+    flow [b,2,h,w] (times flow_scale) -> (out [b,c,h,w], mask2 [b,1,h,w]); all fp32, GPU, contiguous."""
+    for n, t in (("src", src), ("depth", depth), ("flow", flow)) + ((("mask1", mask1),) if mask1 is not None else ()):
+        _need(t, n, torch.float32)
+        if not t.is_contiguous():
+            raise TcxError(f"bilinear_splat: {n} must be contiguous")
+    b, c, h, w = src.shape
+    if not 1 <= c <= 4 or tuple(depth.shape) != (b, h, w) or tuple(flow.shape) != (b, 2, h, w) or (mask1 is not None and tuple(mask1.shape) != (b, 1, h, w)):
+        raise TcxError("bilinear_splat: shape mismatch (src [b,c<=4,h,w], depth [b,h,w], flow [b,2,h,w], mask1 [b,1,h,w])")
+    f32 = dict(device=src.device, dtype=torch.float32)
+    acc = torch.empty((b * (h + 2) * (w + 2) * 5 + 1,), **f32)
+    out, mask2 = torch.empty((b, c, h, w), **f32), torch.empty((b, 1, h, w), **f32)
+    check(_lib.load().tcx_bilinear_splat(_p(src), _p(mask1), _p(depth), _p(flow), _p(acc), _p(out), _p(mask2), b, c, h, w,
+                                         1 if is_image else 0, float(flow_scale), _stream()), "tcx_bilinear_splat")
+    return out, mask2
+
+
 def warp_forward(frame: torch.Tensor, mask1: Optional[torch.Tensor], depth: torch.Tensor, mats: torch.Tensor,
-                 per_item_max: bool = False, clean_points: bool = False):
+                 per_item_max: bool = False, clean_points: bool = False, return_tdepth: bool = False):
     """frame [b,3,h,w], depth [b,1,h,w], mask1 [b,1,h,w] | None, mats [b,30] (all fp32, GPU, contiguous)
     -> (warped [b,3,h,w], mask2 [b,1,h,w], warped_depth [b,1,h,w], flow [b,2,h,w]).
     per_item_max: each batch item is rendered as its own batch-1 reference call (TCX_WARP_PER_ITEM_MAX);
@@ -586,4 +605,6 @@ def warp_forward(frame: torch.Tensor, mask1: Optional[torch.Tensor], depth: torc
     warped, mask2, wdepth = torch.empty((b, 3, h, w), **f32), torch.empty((b, 1, h, w), **f32), torch.empty((b, 1, h, w), **f32)
     check(_lib.load().tcx_warp_forward(_p(frame), _p(mask1), _p(depth), _p(mats), _p(flow), _p(tdepth), _p(acc), _p(warped),
                                        _p(mask2), _p(wdepth), b, h, w, (1 if per_item_max else 0) | (2 if clean_points else 0), _stream()), "tcx_warp_forward")
+    if return_tdepth:
+        return warped, mask2, wdepth, flow, tdepth
     return warped, mask2, wdepth, flow
