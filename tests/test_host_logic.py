@@ -334,8 +334,10 @@ def test_warper_and_driver_need_a_gpu():
     eye, k = torch.eye(4)[None], torch.eye(3)[None]
     with pytest.raises(TcxError):
         w.forward_warp(f, None, d, eye, eye, k, None, False, twice=False)
-    with pytest.raises(NotImplementedError):
-        Warper(device="cuda:0").forward_warp(f, None, d, eye, eye, k, None, False, twice=True)
+    with pytest.raises(NotImplementedError, match="mask=False"):          # twice=True is built for mask=False only (checked before the device)
+        w.forward_warp(f, None, d, eye, eye, k, None, True, twice=True)
+    with pytest.raises(TcxError):
+        w.forward_warp(f, None, d, eye, eye, k, None, False, twice=True)
 
 
 def test_sincos_table_and_position_rows_match_oracle():
