@@ -179,6 +179,14 @@ int tcx_unpatchify(const void* x, void* out, int32_t B, int32_t F, int32_t C, in
 int tcx_cfg_ddim_step(const void* u, const void* c, const void* x, void* out, int64_t n,
                       float guidance, float alpha_t, float alpha_prev, int32_t pred_dtype, void* stream);
 
+/* K10 with eta > 0 (stochastic DDIM, `DDIMScheduler.step(eta=...)`: the pipeline's `eta` argument, :1073,1166): as tcx_cfg_ddim_step with
+ * the direction coefficient dir_coef = sqrt(1 - a_prev - std^2) in place of sqrt(1 - a_prev) and
+ *   x_prev = bf16r( sqrt_alpha_prev x0 + dir_coef eps + std_dev variance_noise ),  std_dev = eta sqrt((1 - a_prev)/(1 - a_t) (1 - a_t/a_prev)),
+ * variance_noise fp32 [n] = the library's randn_tensor draw.  All five coefficients are the scheduler's fp32 scalars. */
+int tcx_cfg_ddim_eta_step(const void* u, const void* c, const void* x, void* out, int64_t n, float guidance,
+                          float sqrt_alpha_t, float sqrt_beta_t, float sqrt_alpha_prev, float dir_coef, float std_dev,
+                          const float* variance_noise, int32_t pred_dtype, void* stream);
+
 /* ---- K10b: the same fusion for the reference's "DDIM_Cog" sampler (diffusers CogVideoXDDIMScheduler.step, eta = 0,
  * v-prediction):  noise as above;  x0 = bf16r(sqrt_alpha_t * x) - sqrt_beta_t * noise;
  *   x_prev = bf16r( bf16r(coef_sample * x) + coef_x0 * x0 ),   coef_sample = sqrt((1 - a_prev) / (1 - a_t)),

@@ -378,14 +378,16 @@ class DDIMScheduler:
         sa, sb = abar ** 0.5, (1 - abar) ** 0.5
         return (sa * original_samples.to(dt) + sb * noise.to(dt)).float()
 
-    def step(self, p: Prec, model_output: torch.Tensor, timestep: int, sample: torch.Tensor, eta: float = 0.0):
-        """`DDIMScheduler.step` (eta = 0).  `model_output` fp32, `sample` in the activation dtype.
+    def step(self, p: Prec, model_output: torch.Tensor, timestep: int, sample: torch.Tensor, eta: float = 0.0,
+             variance_noise: Optional[torch.Tensor] = None):
+        """`DDIMScheduler.step`.  `model_output` fp32, `sample` in the activation dtype.  eta > 0: std = eta sqrt((1 - a_prev)/(1 - a_t)
+        (1 - a_t/a_prev)), the direction term shrinks to sqrt(1 - a_prev - std^2) eps and std * variance_noise (the library's fp32
+        randn_tensor draw, supplied by the caller) is added.
 
         Type-promotion quirk reproduced: a 0-dim fp32 scalar times a bf16 tensor
         stays bf16, so sqrt(a)*sample and sqrt(1-a)*sample are rounded to bf16 before they
         meet the fp32 model output.
         """
-        assert eta == 0.0
         a_t, a_prev = self.coeffs(int(timestep))
         b_t = 1 - a_t
         sa, sb = a_t ** 0.5, b_t ** 0.5
@@ -398,8 +400,13 @@ class DDIMScheduler:
             eps = model_output
         else:
             raise ValueError(self.prediction_type)
-        direction = (1 - a_prev) ** 0.5 * eps
-        return a_prev ** 0.5 * x0 + direction
+        variance = ((1 - a_prev) / b_t) * (1 - a_t / a_prev)
+        std = eta * variance ** 0.5
+        direction = torch.clamp(1 - a_prev - std ** 2, min=0) ** 0.5 * eps      # clamp: exactly 0 for eta = 1 at a zero-SNR step, -1 ulp in fp32
+        prev = a_prev ** 0.5 * x0 + direction
+        if eta > 0:
+            prev = prev + std * variance_noise
+        return prev
 
 
 class CogVideoXDDIMScheduler(DDIMScheduler):

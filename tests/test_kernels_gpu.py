@@ -375,6 +375,28 @@ def test_cfg_ddim_step_matches_oracle(ops, t):
 
 
 @pytest.mark.parametrize("t", [999, 499, 19])
+def test_cfg_ddim_eta_step_matches_oracle(ops, t):
+    """`tcx_cfg_ddim_eta_step` (stochastic DDIM, eta > 0) through the product scheduler against the oracle's step with the same variance
+    noise; eta = 1 at the last step (final alpha 1: std = 0, the noise has no weight)."""
+    from trajectorycrafter_amd.scheduler import DDIMScheduler
+    g = torch.Generator().manual_seed(300 + t)
+    s, ps = dr.DDIMScheduler(), DDIMScheduler()
+    s.set_timesteps(50), ps.set_timesteps(50)
+    x = bf(torch.randn(1, 13, 16, 12, 18, generator=g))
+    pred = torch.randn(2, 13, 16, 12, 18, generator=g)
+    u, c = pred.chunk(2)
+    for eta in (0.3, 1.0):
+        gd, gr = torch.Generator(device="cuda").manual_seed(11), torch.Generator(device="cuda").manual_seed(11)
+        nz = torch.randn(x.shape, generator=gr, device="cuda", dtype=torch.float32).cpu()
+        ref = s.step(Prec("bf16"), u + 6.0 * (c - u), t, x, eta=eta, variance_noise=nz)
+        d = dev(pred)
+        got = ps.fused_cfg_step(d[:1], d[1:], dev(x), 6.0, t, generator=gd, eta=eta)
+        assert_bf16_close(got, ref, atol=1e-5)
+        assert not torch.equal(got, ps.fused_cfg_step(d[:1], d[1:], dev(x), 6.0, t)) or t == 19
+    assert ps.eta_coeffs(19, 1.0)[4] == 0.0
+
+
+@pytest.mark.parametrize("t", [999, 499, 19])
 def test_cfg_ddim_cog_step_matches_oracle(ops, t):
     """`tcx_cfg_ddim_cog_step` (sampler "DDIM_Cog") vs the oracle's CogVideoXDDIMScheduler.step under the bf16 contract, through
     the product scheduler's `fused_cfg_step`."""

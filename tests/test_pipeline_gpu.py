@@ -170,6 +170,41 @@ def test_pipeline_even_frame_count_and_prompt_batch(setup):
     assert out.shape == (2, 3, 8, 32, 48) and torch.isfinite(out).all()
 
 
+def test_pipeline_stochastic_ddim_eta(setup):
+    """`eta > 0` (the pipeline's `eta` argument, handed to schedulers whose `step` takes it, :521-540, :1073, :1166): `DDIM_Origin` with
+    eta 0.6, 3 CFG steps, the variance noise drawn from the call's generator — against the oracle's DDIMScheduler.step(eta, variance_noise)
+    fed the same draws; eta = 0 is the deterministic result; "DPM++" ignores eta like the reference (its `step` has no such parameter);
+    "DDIM_Cog" refuses it."""
+    from oracle import diffusers_restated as dr
+    from trajectorycrafter_amd import scheduler as S
+    from trajectorycrafter_amd.models.pipeline_trajectorycrafter import TrajCrafter_Pipeline
+    s, tp = setup, setup["tp"]
+    dev = s["dev"]
+    kw = dict(prompt=None, height=32, width=48, num_frames=9, num_inference_steps=3, guidance_scale=6.0,
+              prompt_embeds=tp["prompt_embeds"].to(BF), negative_prompt_embeds=tp["negative_prompt_embeds"].to(BF),
+              latents=tp["latents0"].to(BF), inpaint_latents=s["inpaint"].to(BF), ref_latents=s["ref"].to(BF))
+    lat = s["pipe"](output_type="latent", eta=0.6, generator=torch.Generator(device=dev).manual_seed(5), **kw).videos
+    gref = torch.Generator(device=dev).manual_seed(5)
+    draws = [torch.randn(tp["latents0"].shape, generator=gref, device=dev, dtype=torch.float32).cpu() for _ in range(3)]
+
+    class _Eta(dr.DDIMScheduler):
+        def step(self, p, model_output, timestep, sample):
+            i = self.timesteps.tolist().index(int(timestep))
+            return super().step(p, model_output, timestep, sample, eta=0.6, variance_noise=draws[i])
+    args = (s["wt"], s["tr_cfg"], tp["latents0"].to(BF).float(), tp["prompt_embeds"].to(BF).float(), tp["negative_prompt_embeds"].to(BF).float(),
+            s["inpaint"].to(BF).float(), s["ref"].to(BF).float(), 32, 48, 3, 6.0)
+    con, ex = opl.denoise(*args, prec="bf16", scheduler=_Eta()), opl.denoise(*args, prec="fp32", scheduler=_Eta())
+    _check_deep(lat, con, ex, "pipeline latents, DDIM eta 0.6 (3 steps)")
+    det = s["pipe"](output_type="latent", **kw).videos
+    assert not torch.equal(lat, det)
+    assert torch.equal(s["pipe"](output_type="latent", eta=0.0, generator=torch.Generator(device=dev).manual_seed(5), **kw).videos, det)
+    dpm = TrajCrafter_Pipeline(None, None, s["pipe"].vae, s["pipe"].transformer, S.DPMSolverMultistepScheduler())
+    assert torch.equal(dpm(output_type="latent", eta=0.6, **kw).videos, dpm(output_type="latent", **kw).videos)
+    cog = TrajCrafter_Pipeline(None, None, s["pipe"].vae, s["pipe"].transformer, S.CogVideoXDDIMScheduler())
+    with pytest.raises(NotImplementedError, match="DDIM_Origin"):
+        cog(output_type="latent", eta=0.6, **kw)
+
+
 def test_pipeline_error_surface(setup):
     s, tp = setup, setup["tp"]
     pe = tp["prompt_embeds"].to(BF)
@@ -231,7 +266,7 @@ def test_pipeline_strength_below_one_matches_oracle(setup):
     with pytest.raises(ValueError, match="pass `video=`"):
         pipe(**{k: v for k, v in kw.items() if k != "video"})
     with pytest.raises(ValueError, match="eta"):
-        pipe(**dict(kw, eta=0.5))
+        pipe(**dict(kw, eta=1.5))
 
 
 @pytest.mark.parametrize("name", ["Euler", "Euler A", "DPM++", "PNDM"])

@@ -40,6 +40,7 @@ SIGNATURES = {
     "tcx_unpatchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "tcx_cfg_ddim_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _vp],
     "tcx_cfg_ddim_cog_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp],
+    "tcx_cfg_ddim_eta_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _i32, _vp],
     "tcx_cfg_sigma_step": [_vp, _vp, _vp, _vp, _i64, _f32, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
     "tcx_div_bf16": [_vp, _vp, _i64, _f32, _vp],
     "tcx_cfg_pndm_step": [_vp, _vp, _vp, _vp, _i64, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],

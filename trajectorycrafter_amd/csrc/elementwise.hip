@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const uint16_t* x, void
 
 template <bool PRED_F32>
 __global__ __launch_bounds__(256) void cfg_ddim_kernel(const void* u, const void* c, const uint16_t* x, uint16_t* out,
-                                                       int64_t n, float g, float sa, float sb, float sap, float sbp) {
+                                                       int64_t n, float g, float sa, float sb, float sap, float sbp,
+                                                       const float* vnoise = nullptr, float std_dev = 0.f) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float uu, cc = 0.f;
         if constexpr (PRED_F32) {
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const void* u, const void
         // 0-dim fp32 scalar * bf16 tensor stays bf16 in the reference (SURVEY 8c promotion quirk)
         const float x0 = round_bf16(sa * xs) - sb * noise;
         const float eps = sa * noise + round_bf16(sb * xs);
-        const float prev = sap * x0 + sbp * eps;
+        float prev = sap * x0 + sbp * eps;
+        if (vnoise) prev = prev + std_dev * vnoise[i];          // eta > 0: sbp is sqrt(1 - a_prev - std^2), + std * N(0, 1)
         out[i] = (uint16_t)(pack_bf16(prev, 0.f) & 0xffff);
     }
 }
@@ -496,6 +498,24 @@ extern "C" int tcx_cfg_ddim_step(const void* u, const void* c, const void* x, vo
         hipLaunchKernelGGL(cfg_ddim_kernel<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, sa, sb, sap, sbp);
     else
         hipLaunchKernelGGL(cfg_ddim_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, c, (const uint16_t*)x, (uint16_t*)out, n, guidance, sa, sb, sap, sbp);
+    TCX_LAUNCH_RET();
+}
+
+extern "C" int tcx_cfg_ddim_eta_step(const void* u, const void* c, const void* x, void* out, int64_t n, float guidance,
+                                     float sqrt_alpha_t, float sqrt_beta_t, float sqrt_alpha_prev, float dir_coef, float std_dev,
+                                     const float* variance_noise, int32_t pred_dtype, void* stream) {
+    TCX_CHECK(u && x && out && variance_noise, TCX_E_NULL, "tcx_cfg_ddim_eta_step: null pointer");
+    TCX_CHECK(n > 0, TCX_E_SHAPE, "tcx_cfg_ddim_eta_step: n must be positive");
+    TCX_CHECK(pred_dtype == TCX_BF16 || pred_dtype == TCX_F32, TCX_E_DTYPE, "tcx_cfg_ddim_eta_step: bad pred_dtype %d", pred_dtype);
+    TCX_CHECK(sqrt_alpha_t >= 0.f && sqrt_alpha_t <= 1.f && sqrt_beta_t >= 0.f && sqrt_beta_t <= 1.f && sqrt_alpha_prev >= 0.f &&
+                  sqrt_alpha_prev <= 1.f && dir_coef >= 0.f && dir_coef <= 1.f && std_dev >= 0.f && std_dev <= 1.f, TCX_E_SHAPE,
+              "tcx_cfg_ddim_eta_step: coefficients must be in [0, 1] (a NaN direction coefficient means eta too large for this step)");
+    if (pred_dtype == TCX_F32)
+        hipLaunchKernelGGL(cfg_ddim_kernel<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, c, (const uint16_t*)x, (uint16_t*)out, n,
+                           guidance, sqrt_alpha_t, sqrt_beta_t, sqrt_alpha_prev, dir_coef, variance_noise, std_dev);
+    else
+        hipLaunchKernelGGL(cfg_ddim_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, c, (const uint16_t*)x, (uint16_t*)out, n,
+                           guidance, sqrt_alpha_t, sqrt_beta_t, sqrt_alpha_prev, dir_coef, variance_noise, std_dev);
     TCX_LAUNCH_RET();
 }
 

@@ -110,7 +110,8 @@ class DenoiseState:
     do_cfg: bool
     guidance_scale: float
     use_dynamic_cfg: bool = False
-    generator: Optional[torch.Generator] = None   # the call's generator: "Euler A" draws its per-step noise from it (:1073, :1166)
+    generator: Optional[torch.Generator] = None   # the call's generator: "Euler A" / eta > 0 draw their per-step noise from it (:1073, :1166)
+    eta: float = 0.0                              # handed to schedulers whose `step` takes it (DDIM), ignored by the others (:521-540)
 
 
 class TrajCrafter_Pipeline:
@@ -451,8 +452,8 @@ class TrajCrafter_Pipeline:
         if num_frames > 49:
             raise ValueError("The number of frames must be less than 49 for now due to static positional embeddings. "
                              "This will be updated in the future to remove this limitation.")
-        if eta != 0.0:
-            raise ValueError("only eta = 0 (deterministic DDIM, the reference's inference setting) is implemented")
+        if not 0.0 <= eta <= 1.0:
+            raise ValueError(f"`eta` must be in [0, 1], got {eta}")
         if not 0.0 < strength <= 1.0:
             raise ValueError(f"`strength` must be in (0, 1], got {strength}")
         num_videos_per_prompt = 1
@@ -518,7 +519,8 @@ class TrajCrafter_Pipeline:
                             ref_input=ref_input.contiguous(), image_rotary_emb=image_rotary_emb,
                             timesteps=[int(t) for t in timesteps.tolist()], num_inference_steps=num_inference_steps,
                             batch_size=batch_size, do_cfg=do_cfg, guidance_scale=float(guidance_scale),
-                            use_dynamic_cfg=use_dynamic_cfg, generator=generator if not isinstance(generator, list) else generator[0])
+                            use_dynamic_cfg=use_dynamic_cfg, generator=generator if not isinstance(generator, list) else generator[0],
+                            eta=float(eta))
 
     @torch.no_grad()
     def denoise_step(self, st: "DenoiseState", t: int) -> torch.Tensor:
@@ -534,11 +536,14 @@ class TrajCrafter_Pipeline:
         if st.use_dynamic_cfg:                                                     # :1142-1156
             n = st.num_inference_steps
             self._guidance_scale = 1 + st.guidance_scale * ((1 - math.cos(math.pi * ((n - t) / n) ** 5.0)) / 2)
+        skw = {"generator": st.generator}                                          # prepare_extra_step_kwargs (:521-540)
+        if st.eta and getattr(self.scheduler, "accepts_eta", False):
+            skw["eta"] = st.eta
         if st.do_cfg:                                                              # :1157-1178 fused, per scheduler class
             u, c = noise_pred[:st.batch_size], noise_pred[st.batch_size:]
-            st.latents = self.scheduler.fused_cfg_step(u, c, st.latents, self.guidance_scale, t, generator=st.generator)
+            st.latents = self.scheduler.fused_cfg_step(u, c, st.latents, self.guidance_scale, t, **skw)
         else:
-            st.latents = self.scheduler.fused_cfg_step(noise_pred, None, st.latents, 1.0, t, generator=st.generator)
+            st.latents = self.scheduler.fused_cfg_step(noise_pred, None, st.latents, 1.0, t, **skw)
         return st.latents
 
     def timings(self) -> Dict[str, float]:

@@ -270,6 +270,22 @@ def cfg_ddim_step(uncond: torch.Tensor, cond: Optional[torch.Tensor], x: torch.T
     return out
 
 
+def cfg_ddim_eta_step(uncond: torch.Tensor, cond: Optional[torch.Tensor], x: torch.Tensor, guidance: float, coef, noise: torch.Tensor) -> torch.Tensor:
+    """CFG + `DDIMScheduler.step(eta > 0)`, fused (`tcx_cfg_ddim_eta_step`); coef = (sqrt a_t, sqrt(1 - a_t), sqrt a_prev, direction
+    coefficient, std_dev) from the scheduler, noise = its fp32 variance noise."""
+    _need(x, "x"); _need(noise, "noise", torch.float32)
+    if uncond.dtype not in (BF16, torch.float32):
+        raise TcxError(f"cfg_ddim_eta_step: prediction dtype {uncond.dtype} unsupported")
+    if not (uncond.is_contiguous() and x.is_contiguous() and noise.is_contiguous() and (cond is None or cond.is_contiguous())):
+        raise TcxError("cfg_ddim_eta_step: tensors must be contiguous")
+    if uncond.numel() != x.numel() or noise.numel() != x.numel() or (cond is not None and (cond.numel() != x.numel() or cond.dtype != uncond.dtype)):
+        raise TcxError("cfg_ddim_eta_step: size / dtype mismatch")
+    out = torch.empty_like(x)
+    check(_lib.load().tcx_cfg_ddim_eta_step(_p(uncond), _p(cond), _p(x), _p(out), x.numel(), float(guidance), *[float(v) for v in coef],
+                                            _p(noise), TCX_F32 if uncond.dtype == torch.float32 else TCX_BF16, _stream()), "tcx_cfg_ddim_eta_step")
+    return out
+
+
 def cfg_ddim_cog_step(uncond: torch.Tensor, cond: Optional[torch.Tensor], x: torch.Tensor, guidance: float, sqrt_alpha_t: float,
                       sqrt_beta_t: float, coef_sample: float, coef_x0: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """CFG + `CogVideoXDDIMScheduler.step` (sampler "DDIM_Cog"), fused; coefficients from the scheduler's float64 tables."""

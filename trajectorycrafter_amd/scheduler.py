@@ -95,19 +95,37 @@ class DDIMScheduler:
             sa, sb = sa.unsqueeze(-1), sb.unsqueeze(-1)
         return sa * original_samples + sb * noise
 
+    accepts_eta = True           # the library's `step` has an `eta` parameter (the pipeline passes its own `eta` only to such schedulers, :521-540)
+
+    def eta_coeffs(self, timestep: int, eta: float):
+        """(sqrt a_t, sqrt(1 - a_t), sqrt a_prev, sqrt(1 - a_prev - std^2), std) for `step(eta > 0)`: the library's expressions on 0-dim
+        fp32 tensors — variance = (1 - a_prev)/(1 - a_t) (1 - a_t/a_prev), std = eta sqrt(variance)."""
+        prev = timestep - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[timestep].float()
+        a_prev = (self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod).float()
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        variance = (b_prev / b_t) * (1 - a_t / a_prev)
+        std = eta * variance ** 0.5
+        # eta = 1 at the zero-SNR first step (a_t = 0): 1 - a_prev - std^2 is exactly 0 in real arithmetic and +-1 ulp in fp32 (the schedule
+        # table itself differs in the last bit between hosts) — clamped at 0, where the library would take the root of a negative number
+        return [float(a_t ** 0.5), float(b_t ** 0.5), float(a_prev ** 0.5), float(torch.clamp(1 - a_prev - std ** 2, min=0) ** 0.5), float(std)]
+
     def fused_cfg_step(self, uncond: torch.Tensor, cond: Optional[torch.Tensor], sample: torch.Tensor, guidance: float,
-                       timestep: int, generator=None) -> torch.Tensor:
-        """CFG combine (pipeline :1157-1161) + `step` + the bf16 cast (:1178) as ONE kernel (`tcx_cfg_ddim_step`)."""
+                       timestep: int, generator=None, eta: float = 0.0) -> torch.Tensor:
+        """CFG combine (pipeline :1157-1161) + `step` + the bf16 cast (:1178) as ONE kernel (`tcx_cfg_ddim_step`; eta > 0:
+        `tcx_cfg_ddim_eta_step` with the variance noise drawn like the library's randn_tensor, fp32, from `generator`)."""
         from . import ops
-        a_t, a_prev = self.coeffs(int(timestep))
-        return ops.cfg_ddim_step(uncond, cond, sample, guidance, a_t, a_prev)
+        if eta == 0.0:
+            a_t, a_prev = self.coeffs(int(timestep))
+            return ops.cfg_ddim_step(uncond, cond, sample, guidance, a_t, a_prev)
+        gdev = generator.device if generator is not None else sample.device
+        noise = torch.randn(sample.shape, generator=generator, device=gdev, dtype=torch.float32).to(sample.device)
+        return ops.cfg_ddim_eta_step(uncond, cond, sample, guidance, self.eta_coeffs(int(timestep), float(eta)), noise)
 
     def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, eta: float = 0.0,
              generator=None, return_dict: bool = False):
         """diffusers-shaped step (no guidance): prev_sample = DDIM(model_output, sample), bf16 on the GPU."""
-        if eta != 0.0:
-            raise ValueError("only eta = 0 (deterministic DDIM) is implemented")
-        return (self.fused_cfg_step(model_output.contiguous(), None, sample.contiguous(), 1.0, int(timestep)),)
+        return (self.fused_cfg_step(model_output.contiguous(), None, sample.contiguous(), 1.0, int(timestep), generator=generator, eta=eta),)
 
 
 class CogVideoXDDIMScheduler(DDIMScheduler):
@@ -143,8 +161,10 @@ class CogVideoXDDIMScheduler(DDIMScheduler):
         ca = ((1 - a_prev) / (1 - a_t)) ** 0.5
         return a_t ** 0.5, (1 - a_t) ** 0.5, ca, a_prev ** 0.5 - a_t ** 0.5 * ca
 
-    def fused_cfg_step(self, uncond, cond, sample, guidance: float, timestep: int, generator=None) -> torch.Tensor:
+    def fused_cfg_step(self, uncond, cond, sample, guidance: float, timestep: int, generator=None, eta: float = 0.0) -> torch.Tensor:
         from . import ops
+        if eta != 0.0:
+            raise NotImplementedError("eta > 0 is built for 'DDIM_Origin' (scheduler.DDIMScheduler) only")
         sa, sb, ca, cb = self.step_coeffs(timestep)
         return ops.cfg_ddim_cog_step(uncond, cond, sample, guidance, sa, sb, ca, cb)
 
