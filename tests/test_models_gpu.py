@@ -304,6 +304,11 @@ def test_vae_encode_tiny(golden, gpu):
     g = torch.Generator(device="cuda").manual_seed(1)
     smp = post.sample(g)
     assert smp.shape == post.mean.shape and torch.isfinite(smp.float()).all()
+    # forward = encode -> mode / sample -> decode (:1394-1410)
+    rt = vae(video.to(gpu))
+    assert torch.equal(rt.sample, vae.decode(post.mode()).sample) and rt.sample.shape == video.shape
+    rt2 = vae(video.to(gpu), sample_posterior=True, return_dict=False, generator=torch.Generator(device="cuda").manual_seed(1))
+    assert isinstance(rt2, tuple) and torch.equal(rt2[0].sample, vae.decode(smp).sample)
     # single frame path (:1193-1197)
     p1 = vae.encode(video[:, :, :1].to(gpu)).latent_dist
     r1 = ovae.vae_encode(sdf, cfg, video[:, :, :1].float(), prec="bf16")

@@ -589,6 +589,18 @@ class AutoencoderKLCogVideoX(ModelMixin, ConfigMixin):
         return frames
 
     @torch.no_grad()
+    def forward(self, sample: torch.Tensor, sample_posterior: bool = False, return_dict: bool = True,
+                generator: Optional[torch.Generator] = None):
+        """reference :1394-1410: the autoencoding round trip encode -> posterior sample / mode -> decode.  Like the reference it returns
+        what `decode` returns (a DecoderOutput), or a 1-tuple of it with return_dict=False."""
+        posterior = self.encode(sample).latent_dist
+        z = posterior.sample(generator=generator) if sample_posterior else posterior.mode()
+        dec = self.decode(z)
+        if not return_dict:
+            return (dec,)
+        return dec
+
+    @torch.no_grad()
     def encode(self, x: torch.Tensor, return_dict: bool = True):
         """reference :1176-1215: x [N,3,F,H,W] bf16 in [-1,1] -> posterior over [N,16,T,H/8,W/8] (4-frame chunks
         with the remainder folded into the first, conv caches carried across chunks)."""
