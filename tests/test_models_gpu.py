@@ -259,6 +259,47 @@ def test_vae_tiled_decode_tiny(golden, gpu):
     vae.disable_slicing()
 
 
+def test_vae_submodule_and_blend_api(golden, gpu):
+    """The reference's names for the pieces: `vae.decoder(z)` / `vae.encoder(x)` on NCTHW tensors (one chunk), `_decode`,
+    `tiled_decode` regardless of `use_tiling`, `blend_v` / `blend_h` on [N,C,T,H,W] tensors (in place on b)."""
+    from trajectorycrafter_amd.models.autoencoder_magvit import AutoencoderKLCogVideoX
+    t, meta = golden("vae_tiled_tiny.safetensors")
+    tv, _ = golden(meta["weights"])
+    cfg = ast.literal_eval(meta["config"])
+    vae = AutoencoderKLCogVideoX(**cfg)
+    vae.load_state_dict(_weights(tv), strict=True)
+    vae = vae.to(gpu, BF).eval()
+    z = t["z"].to(gpu, BF)
+    full = vae.decode(z).sample
+    assert torch.equal(vae._decode(z).sample, full) and torch.equal(vae._decode(z, return_dict=False)[0], full)
+    vae._clear_fake_context_parallel_cache()
+    first = vae.decoder(z[:, :, :3].contiguous())                          # the first chunk of decode (frame 0 replicated)
+    second = vae.decoder(z[:, :, 3:].contiguous())                         # the second one through the conv caches the first left
+    vae._clear_fake_context_parallel_cache()
+    assert torch.equal(torch.cat([first, second], dim=2), full)
+    x = (full[:, :, :9].float().clamp(-1, 1)).to(BF)
+    mom = vae.encoder(x[:, :, :5].contiguous())
+    mom2 = vae.encoder(x[:, :, 5:9].contiguous())
+    vae._clear_fake_context_parallel_cache()
+    post = vae.encode(x).latent_dist
+    assert torch.equal(torch.cat([mom, mom2], dim=2)[:, :16], post.mean)
+    assert not vae.use_tiling
+    tiled = vae.tiled_decode(z).sample
+    vae.enable_tiling()
+    assert torch.equal(tiled, vae.decode(z).sample)
+    vae.disable_tiling()
+    a, b = full[:, :, :, :20].clone(), full[:, :, :, 30:60].clone()
+    want = b.clone()
+    for y in range(8):
+        want[:, :, :, y, :] = a[:, :, :, -8 + y, :] * (1 - y / 8) + want[:, :, :, y, :] * (y / 8)
+    assert vae.blend_v(a, b, 8) is b and torch.equal(b, want)
+    a, b = full[..., :12].clone(), full[..., 20:50].clone()
+    want = b.clone()
+    for xx in range(5):
+        want[..., xx] = a[..., -5 + xx] * (1 - xx / 5) + want[..., xx] * (xx / 5)
+    assert torch.equal(vae.blend_h(a, b, 5), want)
+
+
 def test_blend_ramp_bit_exact(gpu):
     """tcx_blend_ramp_bf16 against the reference's eager bf16 loop (blend_v / blend_h, autoencoder_magvit.py:1282-1301) run by
     torch on the device: same three roundings per element -> identical bits; ragged extents (min with both tile sizes)."""

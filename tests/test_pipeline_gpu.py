@@ -205,6 +205,24 @@ def test_pipeline_stochastic_ddim_eta(setup):
         cog(output_type="latent", eta=0.6, **kw)
 
 
+def test_pipeline_helper_methods(setup):
+    """`prepare_extra_step_kwargs` (eta only for schedulers whose step takes it), `prepare_mask_latents` (VAE posterior mode times the
+    scaling factor, per batch item), `fuse_qkv_projections` / `unfuse_qkv_projections` — reference :459-506, :521-540, :1218-1226."""
+    from trajectorycrafter_amd import scheduler as S
+    from trajectorycrafter_amd.models.pipeline_trajectorycrafter import TrajCrafter_Pipeline
+    s, tp = setup, setup["tp"]
+    pipe, dev = s["pipe"], s["dev"]
+    assert pipe.prepare_extra_step_kwargs(None, 0.3) == {"generator": None, "eta": 0.3}
+    dpm = TrajCrafter_Pipeline(None, None, pipe.vae, pipe.transformer, S.DPMSolverMultistepScheduler())
+    assert dpm.prepare_extra_step_kwargs(None, 0.3) == {"generator": None}
+    vid = (tp["video"] * 2 - 1).to(BF)
+    mask_lat, mv_lat = pipe.prepare_mask_latents(None, vid, 1, 32, 48, BF, dev, None, True, 0.0563)
+    assert mask_lat is None and mv_lat.shape == (1, 16, 3, 4, 6)
+    want = pipe.vae.encode(vid.to(dev))[0].mode() * pipe.vae.config.scaling_factor
+    assert torch.equal(mv_lat, want)
+    pipe.fuse_qkv_projections(); pipe.unfuse_qkv_projections()
+
+
 def test_pipeline_error_surface(setup):
     s, tp = setup, setup["tp"]
     pe = tp["prompt_embeds"].to(BF)

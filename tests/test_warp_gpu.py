@@ -120,6 +120,29 @@ def test_bilinear_splat_matches_oracle(c, is_image, with_mask, scale):
         ops.bilinear_splat(torch.zeros(1, 5, 4, 4, device="cuda"), None, torch.ones(1, 4, 4, device="cuda"), torch.zeros(1, 2, 4, 4, device="cuda"), True)
 
 
+def test_warper_public_helpers(warper):
+    """`Warper.bilinear_splatting` (depth [b,1,h,w] or [b,h,w], flow12_mask multiplying the weights), `create_grid`,
+    `camera_intrinsic_transform`, `get_device` — the reference's helper surface (models/utils.py:422-583, 628-682)."""
+    from trajectorycrafter_amd.models.utils import Warper
+    g = torch.Generator().manual_seed(2)
+    b, h, w = 1, 24, 32
+    src = torch.rand(b, 3, h, w, generator=g) * 2 - 1
+    depth = 1 + torch.rand(b, 1, h, w, generator=g)
+    flow = (torch.rand(b, 2, h, w, generator=g) - 0.5) * 5
+    m1 = (torch.rand(b, 1, h, w, generator=g) > 0.3).float()
+    fm = (torch.rand(b, 1, h, w, generator=g) > 0.3).float()
+    got, gm = warper.bilinear_splatting(src, m1, depth, flow, fm, is_image=True)
+    want, wm = owarp.bilinear_splat(src, m1 * fm, depth[:, 0], flow, True)
+    assert float((gm.cpu() != wm).float().mean()) <= 2e-3
+    same = (gm.cpu() == wm).expand_as(want)
+    assert float((got.cpu()[same] - want[same]).abs().max()) <= 5e-2
+    grid = Warper.create_grid(2, 3, 4)
+    assert grid.shape == (2, 2, 3, 4) and grid[1, 0, 2].tolist() == [0, 1, 2, 3] and grid[0, 1, :, 0].tolist() == [0, 1, 2]
+    k = Warper.camera_intrinsic_transform(1280, 720, (10, 20))
+    assert k.shape == (4, 4) and k[0, 0] == 2100 and k[0, 2] == 620.0 and k[1, 2] == 350.0
+    assert Warper.get_device("cpu").type == "cpu" and Warper.get_device("gpu0") == torch.device("cuda:0")
+
+
 def test_forward_warp_mask_true_cleans_points(warper):
     """forward_warp(mask=True): holes dilated 5x5 inside the resolve kernel (reference clean_points :585-626)."""
     frame, _, depth, t1, t2, k = _scene(1, 60, 90, 21, False)

@@ -308,6 +308,10 @@ class CogVideoXEncoder3D(nn.Module):
         self.conv_act = nn.SiLU()
         self.conv_out = CogVideoXCausalConv3d(block_out_channels[-1], 2 * out_channels, kernel_size=3, pad_mode=pad_mode)
 
+    def forward(self, sample: torch.Tensor, temb=None) -> torch.Tensor:
+        """reference :773-800 on its NCTHW layout (one temporal chunk; the conv caches persist across calls like the reference's)."""
+        return self.forward_cl(_pad_channels(ops.ncthw_to_cl(sample, 1.0))).permute(0, 4, 1, 2, 3).contiguous()
+
     def forward_cl(self, x: torch.Tensor) -> torch.Tensor:
         """x channels-last [N,T,H,W,3(+pad)] -> moments [N,T',H/8,W/8,32] (reference :773-800)."""
         h = self.conv_in.forward_cl(x)
@@ -345,6 +349,10 @@ class CogVideoXDecoder3D(nn.Module):
         self.norm_out = CogVideoXSpatialNorm3D(rev[-1], in_channels, groups=norm_num_groups)
         self.conv_act = nn.SiLU()
         self.conv_out = CogVideoXCausalConv3d(rev[-1], out_channels, kernel_size=3, pad_mode=pad_mode)
+
+    def forward(self, sample: torch.Tensor, temb=None) -> torch.Tensor:
+        """reference :917-953 on its NCTHW layout (one temporal chunk; the conv caches persist across calls like the reference's)."""
+        return self.forward_cl(ops.ncthw_to_cl(sample, 1.0)).permute(0, 4, 1, 2, 3).contiguous()
 
     def forward_cl(self, z: torch.Tensor) -> torch.Tensor:
         """z channels-last [N,T,h,w,16] -> [N,T',8h,8w,3] (reference :917-953)."""
@@ -539,6 +547,33 @@ class AutoencoderKLCogVideoX(ModelMixin, ConfigMixin):
                 result_row.append(tile[:, :, :limit_h, :limit_w])
             result_rows.append(torch.cat(result_row, dim=3))
         return torch.cat(result_rows, dim=2)
+
+    # the reference's names for the pieces of decode (:1217-1253, :1282-1392), on its NCTHW tensors
+    @torch.no_grad()
+    def _decode(self, z: torch.Tensor, return_dict: bool = True):
+        return self.decode(z, return_dict=return_dict)
+
+    @torch.no_grad()
+    def tiled_decode(self, z: torch.Tensor, return_dict: bool = True):
+        """reference :1303-1392 regardless of `use_tiling` / the size test of `_decode` (:1222-1225)."""
+        if not z.is_cuda or z.dtype != BF16 or self.dtype != BF16:
+            raise TcxError("AutoencoderKLCogVideoX.tiled_decode: needs bf16 latents and weights on the GPU; no CPU fallback")
+        dec = self._tiled_decode_cl(ops.ncthw_to_cl(z, 1.0)).permute(0, 4, 1, 2, 3).contiguous()
+        return DecoderOutput(sample=dec) if return_dict else (dec,)
+
+    def blend_v(self, a: torch.Tensor, b: torch.Tensor, blend_extent: int) -> torch.Tensor:
+        """reference :1282-1291 on [N,C,T,H,W] bf16 tensors: the first rows of `b` ramp from the last rows of `a` (in place on b)."""
+        return self._blend(a, b, blend_extent, 2)
+
+    def blend_h(self, a: torch.Tensor, b: torch.Tensor, blend_extent: int) -> torch.Tensor:
+        """reference :1293-1301: the same along the width."""
+        return self._blend(a, b, blend_extent, 3)
+
+    def _blend(self, a, b, blend_extent, dim_cl):
+        acl, bcl = a.permute(0, 2, 3, 4, 1).contiguous(), b.permute(0, 2, 3, 4, 1).contiguous()
+        ops.blend_ramp(acl, bcl, blend_extent, dim_cl)
+        b.copy_(bcl.permute(0, 4, 1, 2, 3))
+        return b
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):

@@ -318,6 +318,40 @@ class TrajCrafter_Pipeline:
             y = (y >= 0.5).to(y.dtype)
         return y.reshape(b, f, c, height, width).permute(0, 2, 1, 3, 4)
 
+    def prepare_extra_step_kwargs(self, generator, eta):
+        """reference :521-540: what the loop hands `scheduler.step` besides (model_output, t, sample) — `eta` only to schedulers whose
+        step takes it (the DDIM pair), `generator` to those that draw (here: every `fused_cfg_step` accepts it)."""
+        kw = {"generator": generator}
+        if getattr(self.scheduler, "accepts_eta", False):
+            kw["eta"] = eta
+        return kw
+
+    def prepare_mask_latents(self, mask, masked_image, batch_size, height, width, dtype, device, generator,
+                             do_classifier_free_guidance, noise_aug_strength):
+        """reference :459-506: VAE-encode (posterior mode, times scaling_factor) a mask video and / or a masked video, one batch item
+        at a time like the reference; `add_noise_in_inpaint_model` noises the masked video first.  (`__call__` does the same inside
+        `_build_conditioning`, where the mask is resized instead of encoded, :991-996.)"""
+        sf = self.vae.config.scaling_factor
+
+        def enc(x):
+            x = x.to(device=device, dtype=BF16)
+            return torch.cat([self.vae.encode(x[i:i + 1])[0].mode() for i in range(x.shape[0])], dim=0) * sf
+
+        mask = enc(mask) if mask is not None else None
+        masked_image_latents = None
+        if masked_image is not None:
+            if self.transformer.config.add_noise_in_inpaint_model:
+                masked_image = add_noise_to_reference_video(masked_image, ratio=noise_aug_strength)
+            masked_image_latents = enc(masked_image)
+        return mask, masked_image_latents
+
+    def fuse_qkv_projections(self) -> None:
+        """reference :1218-1222 (delegates to the transformer; the HIP model always runs one fused QKV GEMM)."""
+        self.transformer.fuse_qkv_projections()
+
+    def unfuse_qkv_projections(self) -> None:
+        self.transformer.unfuse_qkv_projections()
+
     def _build_conditioning(self, video, mask_video, reference, height, width, do_cfg, dtype, device,
                             noise_aug_strength: Optional[float] = 0.0563, masked_video_latents: Optional[torch.Tensor] = None):
         """reference :862-897 and :927-1028: pixels -> (inpaint_latents [B,T,17,h,w], ref_latents [B,Tr,16,h,w]) through

@@ -60,3 +60,45 @@ class Warper:
         twice_frame1, twice_mask1 = ops.bilinear_splat(warped2, mask2, d2, warped_flow, is_image=True, flow_scale=-1.0)
         twice_depth1, _ = ops.bilinear_splat(wdepth2, mask2, d2, warped_flow, is_image=False, flow_scale=-1.0)
         return twice_frame1, twice_mask1, twice_depth1, None
+
+    # ---- the reference's other public helpers that have a place on this path ----
+    def bilinear_splatting(self, frame1: torch.Tensor, mask1: Optional[torch.Tensor], depth1: torch.Tensor, flow12: torch.Tensor,
+                           flow12_mask: Optional[torch.Tensor] = None, is_image: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """reference :422-583 on `tcx_bilinear_splat`: frame1 [b,c<=4,h,w], depth1 [b,h,w] (the reference's callers pass
+        `trans_depth1`, :277-291), flow12 [b,2,h,w] -> (warped_frame2, mask2).  `flow12_mask` multiplies the weights like mask1 (:497-515)."""
+        if self.device.type != "cuda":
+            raise TcxError("Warper: the HIP splat needs a GPU device (no CPU fallback; use oracle.warp on the CPU)")
+        to = dict(device=self.device, dtype=self.dtype)
+        m = None if mask1 is None else mask1.to(**to)
+        if flow12_mask is not None:
+            m = flow12_mask.to(**to) if m is None else m * flow12_mask.to(**to)
+        d = depth1.to(**to)
+        if d.dim() == 4:
+            d = d[:, 0]
+        return ops.bilinear_splat(frame1.to(**to).contiguous(), None if m is None else m.contiguous(), d.contiguous(),
+                                  flow12.to(**to).contiguous(), is_image=bool(is_image))
+
+    @staticmethod
+    def create_grid(b: int, h: int, w: int) -> torch.Tensor:
+        """reference :628-636: [b, 2, h, w] of (x, y) pixel coordinates (int64, CPU)."""
+        ys, xs = torch.meshgrid(torch.arange(0, h), torch.arange(0, w), indexing="ij")
+        return torch.stack([xs, ys], dim=0)[None].repeat([b, 1, 1, 1])
+
+    @staticmethod
+    def camera_intrinsic_transform(capture_width=1920, capture_height=1080, patch_start_point: tuple = (0, 0)):
+        """reference :656-666: the 4x4 intrinsic matrix (focal 2100) of a crop starting at patch_start_point = (y, x)."""
+        import numpy
+        start_y, start_x = patch_start_point
+        k = numpy.eye(4)
+        k[0, 0] = k[1, 1] = 2100
+        k[0, 2] = capture_width / 2.0 - start_x
+        k[1, 2] = capture_height / 2.0 - start_y
+        return k
+
+    @staticmethod
+    def get_device(device: str):
+        """reference :668-682: 'cpu' | 'gpuN' -> torch.device."""
+        if device.startswith("gpu") and torch.cuda.is_available():
+            return torch.device(f"cuda:{int(device[3:])}")
+        return torch.device("cpu")
+
