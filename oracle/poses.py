@@ -49,3 +49,42 @@ def get_poses_target(depths: torch.Tensor, target_pose, num_frames: int, radius_
     poses[:, 2, 3] = poses[:, 2, 3] + radius
     pose_s = poses[anchor_idx:anchor_idx + 1].repeat(num_frames, 1, 1)
     return pose_s, poses, K
+
+
+def txt_interpolation(input_list, n: int, mode: str = "smooth"):
+    """reference models/utils.py:161-171: scipy UnivariateSpline (k = 3, default smoothing) or interp1d over [0, 1]."""
+    from scipy.interpolate import UnivariateSpline, interp1d
+    x = np.linspace(0, 1, len(input_list))
+    if mode == "smooth":
+        f = UnivariateSpline(x, input_list, k=3)
+    elif mode == "linear":
+        f = interp1d(x, input_list)
+    else:
+        raise KeyError(f"Invalid txt interpolation mode: {mode}")
+    return f(np.linspace(0, 1, n))
+
+
+def generate_traj_txt(c2w_anchor: torch.Tensor, phi, theta, r, frame: int) -> torch.Tensor:
+    """reference models/utils.py:174-210: per-frame (theta, phi, r) from the key values of a trajectory file — smoothing spline with
+    the end points pinned for more than 3 keys, linear otherwise — each through `sphere2pose` -> [frame,4,4]."""
+    def interp(keys):
+        if len(keys) > 3:
+            v = txt_interpolation(keys, frame, mode="smooth")
+            v[0], v[-1] = keys[0], keys[-1]
+            return v
+        return txt_interpolation(keys, frame, mode="linear")
+    phis, thetas, rs = interp(phi), interp(theta), interp(r)
+    return torch.cat([sphere2pose(c2w_anchor, np.float32(th), np.float32(ph), np.float32(rr)) for th, ph, rr in zip(thetas, phis, rs)], dim=0)
+
+
+def get_poses_traj(depths: torch.Tensor, theta, phi, r, num_frames: int, radius_scale: float = 1.0, anchor_idx: int = 0):
+    """reference demo.py:538-586, `opts.camera == 'traj'`: the three lines of a trajectory file (theta keys, phi keys, r keys; r in
+    units of the orbit radius) -> (pose_s, pose_t, K)."""
+    radius = depths[0, 0, depths.shape[-2] // 2, depths.shape[-1] // 2].cpu() * radius_scale
+    radius = min(radius, 5)
+    K = torch.tensor([[500, 0.0, 512.0], [0.0, 500, 288.0], [0.0, 0.0, 1.0]]).repeat(num_frames, 1, 1)
+    c2w_init = torch.tensor([[-1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, -1.0, 0.0], [0.0, 0.0, 0.0, 1.0]]).unsqueeze(0)
+    poses = generate_traj_txt(c2w_init, list(phi), list(theta), [float(i) * radius for i in r], num_frames)
+    poses[:, 2, 3] = poses[:, 2, 3] + radius
+    pose_s = poses[anchor_idx:anchor_idx + 1].repeat(num_frames, 1, 1)
+    return pose_s, poses, K

@@ -491,6 +491,17 @@ def make_poses():
             ps.append(generate_traj_specified(c2w_init, th, ph, dr * radius, dx, dy, 49, "cpu"))
         out[f"poses_r{radius}"] = torch.stack(ps).float()
     out["variants"] = torch.tensor(variants, dtype=torch.float32)
+    # `camera == 'traj'`: the reference's own generate_traj_txt on the key values of its two trajectory files (test/trajs/loop1.txt,
+    # loop2.txt: theta keys / phi keys / r keys; read here as data) and on a short, linearly interpolated one; r keys times radius 2.0
+    from models.utils import generate_traj_txt
+    trajs = {"short": ([0, 10, 0], [0, -30, -60], [0, 0.3, 0.1])}
+    for name in ("loop1", "loop2"):
+        with open(os.path.join(REF, "test", "trajs", name + ".txt")) as f:
+            lines = f.readlines()
+        trajs[name] = tuple([float(v) for v in lines[i].split()] for i in range(3))
+    for name, (theta, phi, r) in trajs.items():
+        out[f"traj_{name}_keys_theta"], out[f"traj_{name}_keys_phi"], out[f"traj_{name}_keys_r"] = (torch.tensor(v, dtype=torch.float64) for v in (theta, phi, r))
+        out[f"traj_{name}_poses"] = generate_traj_txt(c2w_init, phi, theta, [v * 2.0 for v in r], 49, "cpu").float()
     save("orbit_poses.safetensors", out,
          dict(source="reference models/utils.py generate_traj_specified(c2w_init, theta, phi, d_r * radius, d_x, d_y, 49, 'cpu')",
               frames=49))

@@ -43,3 +43,25 @@ def test_product_orbit_poses_match_oracle():
     # frame 0 of every orbit is the anchor camera at distance `radius` in front of the scene centre
     ps, pt, _ = orbit_poses(torch.full((1, 1, 4, 4), 2.0), VARIANTS[6], 49)
     assert torch.allclose(pt[0], torch.tensor([[-1.0, 0, 0, 0], [0, 1, 0, 0], [0, 0, -1, 2.0], [0, 0, 0, 1]]))
+
+
+def test_traj_poses_match_reference_fixture_and_oracle(golden, tmp_path):
+    """`camera == 'traj'` (demo.py:566-573, models/utils.py:161-210): the oracle's `generate_traj_txt` is pinned bit for bit by the
+    reference's own output on the key values of its two trajectory files (+ a short, linearly interpolated one); the product's
+    all-frames-at-once `driver.traj_poses` agrees with the oracle's `get_poses_traj` to fp32 trigonometry (<= 2e-6)."""
+    from trajectorycrafter_amd.driver import read_traj_txt, traj_poses
+    t, _ = golden("orbit_poses.safetensors")
+    for name in ("short", "loop1", "loop2"):
+        th, ph, r = (t[f"traj_{name}_keys_{k}"].tolist() for k in ("theta", "phi", "r"))
+        got = op.generate_traj_txt(C2W_INIT, ph, th, [v * 2.0 for v in r], 49)
+        assert torch.equal(got, t[f"traj_{name}_poses"]), name
+        for centre_depth, scale, anchor in ((2.0, 1.0, 0), (7.0, 1.0, 3), (3.0, 0.5, 0)):
+            depths = torch.full((2, 1, 6, 10), 9.0)
+            depths[0, 0, 3, 5] = centre_depth
+            ps, pt, K = traj_poses(depths, th, ph, r, 49, radius_scale=scale, anchor_idx=anchor)
+            os_, ot, oK = op.get_poses_traj(depths, th, ph, r, 49, radius_scale=scale, anchor_idx=anchor)
+            assert pt.shape == (49, 4, 4) and pt.dtype == torch.float32 and torch.equal(K, oK)
+            assert float((pt - ot).abs().max()) <= 2e-6 and float((ps - os_).abs().max()) <= 2e-6
+    f = tmp_path / "traj.txt"
+    f.write_text("0 2 10 15\n0 -3 -10\n0 0.02 0.09 0.16 0.25\n")
+    assert read_traj_txt(str(f)) == ([0.0, 2.0, 10.0, 15.0], [0.0, -3.0, -10.0], [0.0, 0.02, 0.09, 0.16, 0.25])

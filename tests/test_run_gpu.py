@@ -118,3 +118,16 @@ def test_orbits_entry_point_single_process(golden, tmp_path):
     assert got.shape == (2, 3, 9, 32, 48) and torch.equal(got, want.float().cpu())
     bad = _run(["orbits", "--model-dir", str(ckpt), "--clip", clip_file, "--out", out, "--variants", "sideways"])
     assert bad.returncode != 0 and "unknown variants" in bad.stderr
+    # a trajectory file (reference --camera traj --traj_txt, demo.py:566-573): one more variant, named after the file
+    traj = tmp_path / "sweep.txt"
+    traj.write_text("0 4 8 4 0\n0 -10 -25\n0 0.1 0.2 0.1 0\n")
+    out2 = str(tmp_path / "traj.safetensors")
+    r2 = _run(["orbits", "--model-dir", str(ckpt), "--clip", clip_file, "--out", out2, "--traj-txt", str(traj), "--radius", "0.6",
+               "--steps", "2", "--height", "32", "--width", "48"])
+    assert r2.returncode == 0, r2.stdout[-1500:] + r2.stderr[-3000:]
+    assert json.loads(json.loads(r2.stdout.strip().splitlines()[-1])["variants"]) == ["sweep"]
+    from trajectorycrafter_amd.driver import read_traj_txt
+    want2 = run_orbits(pipe, warper, frames, depths, variants=(("sweep", read_traj_txt(str(traj))),), radius=0.6, K=K, sample_size=(32, 48),
+                       prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=2, seed=43, mask=True)
+    got2 = load_file(out2)["frames"]
+    assert got2.shape == (1, 3, 9, 32, 48) and torch.equal(got2, want2.float().cpu()) and not torch.equal(got2[0], got[0])

@@ -26,6 +26,62 @@ ORBIT_VARIANTS = (
 )
 
 
+def _sphere_poses(theta_deg: torch.Tensor, phi_deg: torch.Tensor, r: torch.Tensor, x: Optional[torch.Tensor] = None,
+                  y: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`sphere2pose` (models/utils.py:83-131) of the anchor camera c2w_init (demo.py:553-564) for all frames at once: translate along
+    the world z axis (and x / y), then rotate about x by theta and about y by phi.  fp32 vectors [F] -> [F,4,4]."""
+    n = theta_deg.shape[0]
+    th, ph = torch.deg2rad(theta_deg), torch.deg2rad(phi_deg)
+    c2w = torch.diag(torch.tensor([-1.0, 1.0, -1.0, 1.0])).repeat(n, 1, 1)
+    c2w[:, 2, 3] -= r
+    if x is not None:
+        c2w[:, 1, 3] += y
+        c2w[:, 0, 3] -= x
+    one, zero = torch.ones(n), torch.zeros(n)
+    rows = lambda *v: torch.stack(v, dim=-1)
+    rot_x = torch.stack([rows(one, zero, zero, zero), rows(zero, th.cos(), -th.sin(), zero),
+                         rows(zero, th.sin(), th.cos(), zero), rows(zero, zero, zero, one)], dim=1)
+    rot_y = torch.stack([rows(ph.cos(), zero, ph.sin(), zero), rows(zero, one, zero, zero),
+                         rows(-ph.sin(), zero, ph.cos(), zero), rows(zero, zero, zero, one)], dim=1)
+    return rot_y @ (rot_x @ c2w)
+
+
+def _key_interpolation(keys: Sequence[float], n: int) -> np.ndarray:
+    """`generate_traj_txt`'s per-frame values from the key values of a trajectory file (models/utils.py:161-202): more than 3 keys ->
+    cubic smoothing spline (scipy UnivariateSpline, default smoothing) with the two end points pinned, else piecewise linear."""
+    from scipy.interpolate import UnivariateSpline, interp1d
+    keys = [float(v) for v in keys]
+    x, xn = np.linspace(0, 1, len(keys)), np.linspace(0, 1, n)
+    if len(keys) > 3:
+        v = UnivariateSpline(x, keys, k=3)(xn)
+        v[0], v[-1] = keys[0], keys[-1]
+        return v
+    return interp1d(x, keys)(xn)
+
+
+def traj_poses(depths: torch.Tensor, theta: Sequence[float], phi: Sequence[float], r: Sequence[float], num_frames: int,
+               radius_scale: float = 1.0, anchor_idx: int = 0, device=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """`TrajCrafter.get_poses` with `opts.camera == 'traj'` (demo.py:566-573): the three lines of a trajectory file (test/trajs/*.txt:
+    theta keys, phi keys, r keys in units of the orbit radius) interpolated over the clip (`generate_traj_txt`,
+    models/utils.py:174-210) -> (pose_s, pose_t, K) like `orbit_poses`."""
+    device = depths.device if device is None else torch.device(device)
+    radius = min(float(depths[0, 0, depths.shape[-2] // 2, depths.shape[-1] // 2]) * radius_scale, 5.0)
+    f32 = lambda v: torch.from_numpy(np.asarray(v).astype(np.float32))
+    rs = _key_interpolation([float(v) * np.float32(radius) for v in r], num_frames)
+    poses = _sphere_poses(f32(_key_interpolation(theta, num_frames)), f32(_key_interpolation(phi, num_frames)), f32(rs))
+    poses[:, 2, 3] += np.float32(radius)                                                 # :580
+    K = torch.tensor([[500.0, 0.0, 512.0], [0.0, 500.0, 288.0], [0.0, 0.0, 1.0]]).repeat(num_frames, 1, 1)
+    pose_s = poses[anchor_idx:anchor_idx + 1].repeat(num_frames, 1, 1)
+    return pose_s.to(device), poses.to(device), K.to(device)
+
+
+def read_traj_txt(path: str):
+    """A trajectory file of the reference (test/trajs/loop1.txt): line 1 theta keys, line 2 phi keys, line 3 r keys (demo.py:567-571)."""
+    with open(path) as f:
+        lines = f.readlines()
+    return tuple([float(v) for v in lines[i].split()] for i in range(3))
+
+
 def orbit_poses(depths: torch.Tensor, target_pose: Sequence[float], num_frames: int, radius_scale: float = 1.0,
                 anchor_idx: int = 0, device=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """`TrajCrafter.get_poses` with `opts.camera == 'target'` (demo.py:538-586): the camera moves from the anchor pose to
@@ -37,19 +93,7 @@ def orbit_poses(depths: torch.Tensor, target_pose: Sequence[float], num_frames: 
     radius = min(float(depths[0, 0, depths.shape[-2] // 2, depths.shape[-1] // 2]) * radius_scale, 5.0)
     d_theta, d_phi, d_r, d_x, d_y = (float(v) for v in target_pose)
     lin = lambda end: torch.from_numpy(np.linspace(0, end, num_frames).astype(np.float32))
-    th, ph = torch.deg2rad(lin(d_theta)), torch.deg2rad(lin(d_phi))
-    r, x, y = lin(d_r * np.float32(radius)), lin(d_x), lin(d_y)
-    c2w = torch.diag(torch.tensor([-1.0, 1.0, -1.0, 1.0])).repeat(num_frames, 1, 1)       # c2w_init (:553-564)
-    c2w[:, 2, 3] -= r                                                                    # translate first ... (:88-92)
-    c2w[:, 1, 3] += y
-    c2w[:, 0, 3] -= x
-    one, zero = torch.ones(num_frames), torch.zeros(num_frames)
-    rows = lambda *v: torch.stack(v, dim=-1)
-    rot_x = torch.stack([rows(one, zero, zero, zero), rows(zero, th.cos(), -th.sin(), zero),
-                         rows(zero, th.sin(), th.cos(), zero), rows(zero, zero, zero, one)], dim=1)
-    rot_y = torch.stack([rows(ph.cos(), zero, ph.sin(), zero), rows(zero, one, zero, zero),
-                         rows(-ph.sin(), zero, ph.cos(), zero), rows(zero, zero, zero, one)], dim=1)
-    poses = rot_y @ (rot_x @ c2w)                                                        # ... then rotate (:128-129)
+    poses = _sphere_poses(lin(d_theta), lin(d_phi), lin(d_r * np.float32(radius)), lin(d_x), lin(d_y))
     poses[:, 2, 3] += np.float32(radius)                                                 # :580
     K = torch.tensor([[500.0, 0.0, 512.0], [0.0, 500.0, 288.0], [0.0, 0.0, 1.0]]).repeat(num_frames, 1, 1)   # :545-552
     pose_s = poses[anchor_idx:anchor_idx + 1].repeat(num_frames, 1, 1)
@@ -107,6 +151,8 @@ def run_orbits(pipe, warper: Warper, frames: torch.Tensor, depths: torch.Tensor,
     reassembles the clips; the fp32 frame conversion of `decode_latents` (:514-517) runs on the gathered tensor (bit-identical to
     converting per rank, half the bytes on the wire).  Without an initialised process group this is the reference's sequential loop.
 
+    A variant is (name, (d_theta, d_phi, d_r, d_x, d_y)) — a target pose, `camera == 'target'` — or (name, (theta keys, phi keys,
+    r keys)) — the three lines of a trajectory file, `camera == 'traj'` (demo.py:566-573; `read_traj_txt`).
     frames [F,3,H,W] in [-1,1] and depths [F,1,H,W] come from the conditioning stage (video decode + depth estimator: control
     plane, not on this path).  `K` overrides the reference's hard-wired 1024x576 intrinsics (demo.py:545-552) for other input
     sizes.  Every variant uses `Generator(seed)` like the reference (demo.py:121); the reference's one unseeded draw — the
@@ -120,9 +166,15 @@ def run_orbits(pipe, warper: Warper, frames: torch.Tensor, depths: torch.Tensor,
     n_frames = frames.shape[0]
 
     def run_one(i: int) -> torch.Tensor:
-        d_theta, d_phi, d_r, d_x, d_y = variants[i][1]
-        pose_s, pose_t, k_ref = orbit_poses(depths, (d_theta, d_phi, d_r * radius, d_x, d_y), n_frames, radius_scale,
-                                            device=warper.device)
+        spec = variants[i][1]
+        if len(spec) == 3 and all(hasattr(v, "__len__") for v in spec):          # (theta keys, phi keys, r keys): `camera == 'traj'`
+            theta, phi, r_keys = spec
+            pose_s, pose_t, k_ref = traj_poses(depths, theta, phi, [float(v) * radius for v in r_keys], n_frames, radius_scale,
+                                               device=warper.device)
+        else:                                                                    # (d_theta, d_phi, d_r, d_x, d_y): `camera == 'target'`
+            d_theta, d_phi, d_r, d_x, d_y = spec
+            pose_s, pose_t, k_ref = orbit_poses(depths, (d_theta, d_phi, d_r * radius, d_x, d_y), n_frames, radius_scale,
+                                                device=warper.device)
         video, mask_video, reference = render_conditioning(warper, frames, depths, pose_s, pose_t,
                                                            k_ref if K is None else K.to(warper.device), sample_size, mask)
         torch.manual_seed(seed + 1 + i)                                           # the posterior sample's global RNG, per variant

@@ -132,6 +132,11 @@ def cmd_orbits(a) -> int:
         if unknown:
             raise ValueError(f"unknown variants {unknown}; known: {sorted(table)}")
         variants = tuple((n, table[n]) for n in a.variants.split(","))
+    if a.traj_txt:                                        # reference --camera traj --traj_txt FILE (demo.py:566-573), one variant per file
+        from .driver import read_traj_txt
+        files = a.traj_txt.split(",")
+        trajs = tuple((os.path.splitext(os.path.basename(f))[0], read_traj_txt(f)) for f in files)
+        variants = trajs if not a.variants else variants + trajs
     prompt = header.get("prompt")
     if "prompt_embeds" in clip:
         extra = dict(prompt_embeds=clip["prompt_embeds"].to(torch.bfloat16),
@@ -178,6 +183,8 @@ def parse(argv=None):
     o.add_argument("--radius", type=float, default=1.0, help="reference --radius")
     o.add_argument("--radius-scale", type=float, default=1.0, help="reference --radius_scale")
     o.add_argument("--variants", default=None, help="comma-separated subset of the reference's variant names (default: all eight)")
+    o.add_argument("--traj-txt", default=None, help="comma-separated trajectory files (reference --camera traj --traj_txt: theta / phi / r "
+                                                     "key lines, test/trajs/loop1.txt); alone: only these; with --variants: in addition")
     o.add_argument("--no-mask", action="store_true", help="reference opts.mask = False (inference_orbits.py sets True)")
     return ap.parse_args(argv)
 
