@@ -243,6 +243,79 @@ def cpu_baseline_bounded(args):
 
 
 # ------------------------------------------------------------------------------------------- rank plumbing
+class DataPlane:
+    """State of the data-plane collective (the one all-gather per clip) and the rules for leaving RCCL.
+
+    Every RCCL call runs as a *stage*: on a guard thread (`dp.guarded`, bounded by TCX_RCCL_GUARD_S, default 60 s), followed by a
+    MIN vote over the gloo control group, so all ranks keep RCCL or all fall back to the host-staged gloo gather together — a rank
+    that fails or hangs early never leaves the others inside an RCCL call.  The fallback is LOUD (stderr + `collective_fallback`
+    in the JSON line); TCX_BENCH_RCCL_FATAL=1 turns it into exit code 3."""
+
+    def __init__(self, rank: int, local: int, backend: str):
+        self.rank, self.local, self.backend = rank, local, backend
+        self.group, self.error, self.abandoned = None, None, 0
+        self.guard_s = float(os.environ.get("TCX_RCCL_GUARD_S", 60.0))
+
+    def vote(self, err) -> bool:
+        import torch
+        import torch.distributed as dist
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)                  # gloo, host tensor
+        return int(ok.item()) == 1
+
+    def step(self, fn, what: str):
+        """-> (result, error text or None).  A call that neither returns nor raises within guard_s is reported as hung and its
+        thread abandoned in native code (the process must then leave through os._exit, see `finish`)."""
+        from trajectorycrafter_amd import dp
+        try:
+            return dp.guarded(fn, self.guard_s, what, device=self.local), None
+        except dp.CollectiveHang as e:
+            self.abandoned += 1
+            return None, f"CollectiveHang: {e}"
+        except Exception as e:
+            return None, f"{type(e).__name__}: {str(e)[:400]}"
+
+    def stage(self, fn, what: str):
+        """step + vote; on a lost vote every rank falls back.  -> result (None after a fallback)."""
+        out, err = self.step(fn, what)
+        if not self.vote(err):
+            self.fall_back(err, what)
+            return None
+        return out
+
+    def fall_back(self, err, stage: str) -> None:
+        self.error = err or f"RCCL {stage} failed on another rank (see its stderr)"
+        if err:
+            print(f"[bench] rank {self.rank}: RCCL {stage} FAILED: {err}", file=sys.stderr, flush=True)
+        if os.environ.get("TCX_BENCH_RCCL_FATAL") == "1":
+            sys.stdout.flush(), sys.stderr.flush()
+            os._exit(3)
+        print(f"[bench] rank {self.rank}: ALL RANKS FALL BACK to gloo (host-mediated all-gather) — flagged in the JSON line as "
+              "`collective_fallback`; this is NOT an RCCL measurement", file=sys.stderr, flush=True)
+        self.backend, self.group = "gloo", None
+
+    def finish(self) -> None:
+        import torch.distributed as dist
+        dist.barrier()
+        if self.abandoned:                                          # a thread is still inside a hung RCCL call: no orderly teardown
+            sys.stdout.flush(), sys.stderr.flush()
+            os._exit(0)
+        dist.destroy_process_group()
+
+
+def _init_control_plane(rank):
+    """The gloo control group (rendezvous bounded by dp.DEFAULT_TIMEOUT_S / TCX_DIST_TIMEOUT_S): an unreachable peer ends this
+    rank with an error line and exit code 3 in about two minutes instead of the 600 s kill of the driver."""
+    from trajectorycrafter_amd import dp
+    try:
+        dp.init_distributed("gloo")
+    except Exception as e:
+        print(f"[bench] rank {rank}: init_process_group('gloo') FAILED after <= {dp.dist_timeout().total_seconds():.0f} s: "
+              f"{type(e).__name__}: {str(e)[:500]}", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(3)                                             # a half-built process group can block the normal shutdown
+
+
 def _selftest_rank(args, rank, world):
     """CPU-only rehearsal of the N-rank control flow on gloo (tests/test_bench_launcher.py): rendezvous, barrier, max-reduce
     of the elapsed time, the single all-gather, one JSON line from rank 0."""
@@ -250,21 +323,38 @@ def _selftest_rank(args, rank, world):
     import torch.distributed as dist
     from trajectorycrafter_amd import dp
     if world > 1:
-        dp.init_distributed("gloo")
+        _init_control_plane(rank)
         dist.barrier()
     t0 = time.perf_counter()
     local = torch.full((1, 3, 2, 4, 4), float(43 + rank))
     elapsed = torch.tensor([time.perf_counter() - t0 + 1e-3 * (rank + 1)], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    # the data-plane rules (DataPlane: guard thread + vote + loud fallback) with a stand-in for the RCCL call: TCX_SELFTEST_RCCL =
+    # "ok" | "error" | "hang" | "hang:<rank>" (only that rank's call blocks — the others must still fall back with it)
+    plane = DataPlane(rank, None, "nccl" if world > 1 else "gloo")
+    sim = os.environ.get("TCX_SELFTEST_RCCL", "ok")
+
+    def fake_rccl():
+        if sim == "error":
+            raise RuntimeError("simulated RCCL error")
+        if sim == "hang" or sim == f"hang:{rank}":
+            time.sleep(3600)
+        return "communicator"
+
+    if world > 1:
+        plane.group = plane.stage(fake_rccl, "new_group(simulated)")
     frames = dp.all_gather_cat(local)
     assert frames.shape[0] == world and frames[:, 0, 0, 0, 0].tolist() == [float(43 + r) for r in range(world)]
     if rank == 0:
-        print(json.dumps({"metric": "selftest", "value": world / float(elapsed), "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "gathered": list(frames.shape)}), flush=True)
+        rec = {"metric": "selftest", "value": world / float(elapsed), "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "gathered": list(frames.shape), "collective_backend": plane.backend if world > 1 else None,
+               "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+        if plane.error is not None:
+            rec["collective_fallback"] = f"gloo, because RCCL failed: {plane.error[:400]}"
+        print(json.dumps(rec), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        plane.finish()
 
 
 def run_rank(args):
@@ -291,50 +381,49 @@ def run_rank(args):
     # (host-mediated) LOUDLY: error text on stderr and in the JSON line's top level (`collective_fallback`), so a host-staged gather
     # can never pass for an RCCL scaling number; TCX_BENCH_RCCL_FATAL=1 makes it exit code 3 instead.  TCX_DIST_BACKEND=gloo asks
     # for gloo outright (the one-card rehearsal).
-    backend = os.environ.get("TCX_DIST_BACKEND", "nccl")
-    rccl_error, gather_group = None, None
+    plane = DataPlane(rank, local, os.environ.get("TCX_DIST_BACKEND", "nccl"))
+    devices = None
     if world > 1:
-        try:
-            dp.init_distributed("gloo")
-        except Exception as e:
-            print(f"[bench] rank {rank}: init_process_group('gloo') FAILED: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
-            raise SystemExit(3)
-        if backend == "nccl":
-            try:
-                gather_group = dist.new_group(backend="nccl")
+        _init_control_plane(rank)
+        mine = {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(local), "device_count": torch.cuda.device_count(),
+                "host": socket.gethostname()}
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)                            # gloo: who runs where, printed in config.ranks
+        if plane.backend == "nccl":
+            # separately voted stages: (1) communicator group creation, (2) a one-element all-reduce
+            plane.group = plane.stage(lambda: dist.new_group(backend="nccl", timeout=dp.dist_timeout()), "new_group(nccl)")
+        if plane.backend == "nccl":
+            def probe():
                 one = torch.ones(1, device=device)
-                dist.all_reduce(one, group=gather_group)
+                dist.all_reduce(one, group=plane.group)
                 torch.cuda.synchronize()
                 if float(one.item()) != world:
                     raise RuntimeError(f"RCCL probe all-reduce returned {float(one.item())}, expected {world}")
-            except Exception as e:
-                rccl_error = f"{type(e).__name__}: {e}"
-                print(f"[bench] rank {rank}: RCCL probe (new_group + all_reduce) FAILED: {rccl_error}", file=sys.stderr, flush=True)
-            ok = torch.tensor([0 if rccl_error else 1], dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)                       # gloo, CPU tensor: the collective decision
-            if int(ok.item()) == 0:
-                rccl_error = rccl_error or "RCCL probe failed on another rank (see its stderr)"
-                if os.environ.get("TCX_BENCH_RCCL_FATAL") == "1":
-                    raise SystemExit(3)
-                print(f"[bench] rank {rank}: ALL RANKS FALL BACK to gloo (host-mediated all-gather) — flagged in the JSON line as "
-                      "`collective_fallback`; this is NOT an RCCL measurement", file=sys.stderr, flush=True)
-                backend, gather_group = "gloo", None
-        if backend != "nccl":
-            print(f"[bench] WARNING: collective backend is {backend!r}, not RCCL: the all-gather is host-mediated; this is a rehearsal, "
+            plane.stage(probe, "probe all_reduce")
+        if plane.backend != "nccl":
+            print(f"[bench] WARNING: collective backend is {plane.backend!r}, not RCCL: the all-gather is host-mediated; this is a rehearsal, "
                   "not a scaling measurement", file=sys.stderr, flush=True)
+    def device_sync():
+        # barrier + torch.cuda.synchronize() (driver contract).  Only after an RCCL call has been declared hung — its kernel may
+        # still spin on the card, and a device-wide synchronize would wait for it for ever — the launch stream alone is waited for.
+        if plane.abandoned:
+            torch.cuda.current_stream().synchronize()
+        else:
+            torch.cuda.synchronize()
+
     t_init = time.perf_counter()
     pipe = build_models(args, device)
     inp = make_inputs(args, device, seed=43 + rank)            # one independent trajectory per rank (seeds 43..50)
     st = pipe.prepare_denoise(prompt=None, height=args.height, width=args.width, num_frames=args.frames,
                               num_inference_steps=args.denoise_steps, guidance_scale=6.0, **inp)
-    torch.cuda.synchronize()
+    device_sync()
     t_init = time.perf_counter() - t_init
 
     def barrier():
-        torch.cuda.synchronize()
+        device_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     def timed(fn, reps=1):
         """fn() `reps` times between barrier + synchronize pairs -> seconds, max over ranks."""
@@ -379,9 +468,24 @@ def run_rank(args):
             dec = lambda: pipe.vae.decode_cl_bf16(lat.permute(0, 2, 1, 3, 4), scale=1.0 / pipe.vae.config.scaling_factor)
             dec()
             decode_s, out_cl = timed(dec)
-            gat = lambda: pipe.vae.cl_to_frames(dp.all_gather_cat(out_cl, group=gather_group))
-            gat()                                               # warm-up (RCCL channel set-up)
-            gather_s, frames = timed(gat)                       # THE collective of the path: once per clip
+            # THE collective of the path, once per clip.  RCCL calls run behind the guard (dp.guarded) and every stage is voted over
+            # gloo: warm-up (channel set-up is where a hang would sit), then the timed call.  Host-staged gloo gather otherwise.
+            if plane.backend == "nccl":
+                plane.stage(lambda: dp.all_gather_cat(out_cl, group=plane.group), "all_gather warm-up")
+            if plane.backend == "nccl":
+                last = {}
+
+                def gat():
+                    out, last["err"] = plane.step(lambda: dp.all_gather_cat(out_cl, group=plane.group), "all_gather_into_tensor(nccl)")
+                    return None if out is None else pipe.vae.cl_to_frames(out)
+
+                gather_s, frames = timed(gat)
+                if not plane.vote(last["err"]):
+                    plane.fall_back(last["err"], "all_gather")
+            if plane.backend != "nccl":
+                gat = lambda: pipe.vae.cl_to_frames(dp.all_gather_cat(out_cl.cpu()).to(device))    # default (gloo) group, host tensors
+                gat()
+                gather_s, frames = timed(gat)
         assert frames.shape[0] == world and torch.isfinite(frames).all() and 0.0 <= float(frames.min()) and float(frames.max()) <= 1.0
         frames_shape = list(frames.shape)
 
@@ -416,7 +520,9 @@ def run_rank(args):
                        "value_formula": "n_gpus / (denoise_steps * ms_per_step + decode_ms + allgather_ms) * 1000",
                        "frames": args.frames, "height": args.height, "width": args.width, "denoise_steps": args.denoise_steps,
                        "layers": args.layers, "vae_decode": not args.no_decode, "global_batch_clips": world,
-                       "parallelism": f"dp{world}", "collective_backend": (backend if world > 1 else None), "control_backend": ("gloo" if world > 1 else None), "decode_ms": 1e3 * decode_s, "allgather_ms": 1e3 * gather_s,
+                       "parallelism": f"dp{world}", "collective_backend": (plane.backend if world > 1 else None), "control_backend": ("gloo" if world > 1 else None),
+                       "ranks": devices if world > 1 else [{"rank": 0, "device": torch.cuda.get_device_name(local), "device_count": torch.cuda.device_count()}],
+                       "decode_ms": 1e3 * decode_s, "allgather_ms": 1e3 * gather_s,
                        "clip_seconds": clip_s, "timed_steps_seconds": elapsed, "init_seconds": t_init,
                        "frames_out": frames_shape,
                        "transformer_mfma_frac": (None if fwd_flop is None else
@@ -430,19 +536,21 @@ def run_rank(args):
         dbg = {k: os.environ[k] for k in ("TCX_CONV_GENERIC", "TCX_LIB", "TCX_DIST_BACKEND", "TCX_BENCH_SINGLE_DEVICE") if os.environ.get(k)}
         if dbg:                                                 # switches that change what runs: never unrecorded
             rec["config"]["debug_env"] = dbg
-        if world > 1 and backend != "nccl":
-            rec["collective_backend_warning"] = f"{backend}: host-mediated all-gather, NOT RCCL — rehearsal only"
-        if rccl_error is not None:
-            rec["collective_fallback"] = f"gloo, because RCCL failed to initialise: {rccl_error[:400]}"
+        if world > 1 and plane.backend != "nccl":
+            rec["collective_backend_warning"] = f"{plane.backend}: host-mediated all-gather, NOT RCCL — rehearsal only"
+        if plane.error is not None:
+            rec["collective_fallback"] = f"gloo, because RCCL failed: {plane.error[:400]}"
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline_bounded(args)
         print(json.dumps(rec), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        plane.finish()
 
 
 def main(argv=None):
+    # dmabuf IPC, required for RCCL on this pool: set before torch / the HSA runtime come up, also when a plain torchrun line
+    # (the driver's N > 1 launch) started this process and did not export it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
     if args.cpu_baseline_only:                                  # child process of cpu_baseline_bounded: CPU only

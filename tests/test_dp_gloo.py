@@ -4,6 +4,7 @@ import socket
 import sys
 
 import torch
+import pytest
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -80,3 +81,15 @@ def test_single_process_is_passthrough():
     out = dp.run_trajectories(lambda i: torch.full((1, 2), float(i)), 3)
     assert out[:, 0].tolist() == [0.0, 1.0, 2.0]
     assert dp.shard_indices(8, 3, 4) == [3, 7]
+
+
+def test_guarded_returns_raises_and_times_out():
+    import time
+    from trajectorycrafter_amd import dp
+    assert dp.guarded(lambda: 41 + 1, 5.0, "quick") == 42
+    with pytest.raises(ZeroDivisionError):
+        dp.guarded(lambda: 1 / 0, 5.0, "raises")
+    t0 = time.time()
+    with pytest.raises(dp.CollectiveHang, match="stuck call did not return within 1 s"):
+        dp.guarded(lambda: time.sleep(30), 1.0, "stuck call")
+    assert time.time() - t0 < 5

@@ -37,25 +37,29 @@ def _check(got, ref, ulps=2.0, atol=4e-3, mean_tol=2e-3):
 
 
 def record_parity(rec: dict) -> None:
-    """Append a measured-tolerance record to gpurun_out/r3_parity.jsonl (merged back from the GPU box; DESIGN §4 quotes it)."""
+    """Append a measured-tolerance record to gpurun_out/parity.jsonl (merged back from the GPU box; tools/collect_parity.py turns
+    it into profiles/<round>_parity.json, which DESIGN §4 quotes and which justifies the factors of `_check_deep`)."""
     import json
     import os
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "r3_parity.jsonl"), "a") as f:
+        with open(os.path.join(d, "parity.jsonl"), "a") as f:
             f.write(json.dumps(rec) + "\n")
     except OSError:
         pass
 
 
-def _check_deep(got, contract, exact, what, record=True):
+def _check_deep(got, contract, exact, what, record=True, mean_x=1.15, p999_x=1.3, hc_x=1.5):
     """Deep bf16 pipelines (many rounded layers) diverge element-wise even between two correct
     implementations, because a one-ulp flip early on is amplified downstream.  The criterion that
     still catches real bugs: measured against the reference's own fp32 output (`exact`, from the golden
     fixture), the HIP result must be as accurate as the oracle's bf16 rounding contract —
-      mean|hip - exact| <= 1.5 * mean|contract - exact|,  p99.9|hip - exact| <= 2 * p99.9|contract - exact|,
-    and HIP must sit as close to the contract as the contract sits to the exact result."""
+      mean|hip - exact| <= mean_x * mean|contract - exact|,  p99.9|hip - exact| <= p999_x * p99.9|contract - exact|,
+    and HIP must sit as close to the contract as the contract sits to the exact result (hc_x).
+    Factors (round 4): every record of profiles/r3_parity.json measures mean <= 1.033 x, p99.9 <= 1.030 x,
+    hip-vs-contract <= 1.19 x, so the defaults are 1.15 / 1.3 / 1.5 (they were 1.5 / 2 / 2); a caller that needs more passes its
+    factors explicitly and says which record justifies them.  tools/exp/parity_sensitivity.sh shows what these bounds catch."""
     got, contract, exact = got.float().cpu(), contract.float().cpu(), exact.float().cpu()
     assert got.shape == exact.shape and torch.isfinite(got).all()
     e_hip, e_con, e_hc = (got - exact).abs(), (contract - exact).abs(), (got - contract).abs()
@@ -70,9 +74,9 @@ def _check_deep(got, contract, exact, what, record=True):
            "hip_vs_contract": {"max": float(e_hc.max()), "mean": float(e_hc.mean()), "inside_rtol1e-3_atol1e-4": inside(got, contract)}}
     if record:
         record_parity(rec)
-    assert float(e_hip.mean()) <= 1.5 * float(e_con.mean()) + 1e-5, msg
-    assert q(e_hip) <= 2.0 * q(e_con) + 1e-4, msg
-    assert float(e_hc.mean()) <= 2.0 * float(e_con.mean()) + 1e-5, msg
+    assert float(e_hip.mean()) <= mean_x * float(e_con.mean()) + 1e-5, msg
+    assert q(e_hip) <= p999_x * q(e_con) + 1e-4, msg
+    assert float(e_hc.mean()) <= hc_x * float(e_con.mean()) + 1e-5, msg
     return rec
 
 

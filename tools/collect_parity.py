@@ -1,10 +1,10 @@
-"""gpurun_out/r3_parity.jsonl (appended by tests/test_models_gpu.record_parity during `pytest -m gpu` on the GPU box) -> profiles/<tag>_parity.json:
+"""gpurun_out/parity.jsonl (appended by tests/test_models_gpu.record_parity during `pytest -m gpu` on the GPU box) -> profiles/<tag>_parity.json:
 the last record of every comparison, in first-seen order.   usage: python tools/collect_parity.py [tag]"""
 import json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 recs, order = {}, []
-with open(os.path.join(root, "gpurun_out", "r3_parity.jsonl")) as f:
+with open(os.path.join(root, "gpurun_out", "parity.jsonl")) as f:
     for line in f:
         if line.strip():
             r = json.loads(line)

@@ -9,19 +9,36 @@ reassembles the decoded frames (or the latents) on every rank.
 """
 from __future__ import annotations
 
+import datetime
 import os
-from typing import Callable, List, Sequence, Tuple
+import threading
+from typing import Callable, List, Optional, Sequence, Tuple
 
-import torch
-import torch.distributed as dist
+# dmabuf IPC: without it RCCL fails on this pool with `hipIpcGetMemHandle: invalid argument`.  Set before the HSA runtime starts
+# (first HIP call), also for ranks started by a plain torchrun line that did not export it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch                                  # noqa: E402
+import torch.distributed as dist              # noqa: E402
+
+# An unreachable peer or a stuck RCCL bootstrap must end the job in about two minutes with an error, not sit out torch's
+# 10 / 30-minute defaults (the driver's limit for a bench run is 600 s).  TCX_DIST_TIMEOUT_S overrides.
+DEFAULT_TIMEOUT_S = 120.0
+
+
+def dist_timeout(seconds: Optional[float] = None) -> datetime.timedelta:
+    if seconds is None:
+        seconds = float(os.environ.get("TCX_DIST_TIMEOUT_S", DEFAULT_TIMEOUT_S))
+    return datetime.timedelta(seconds=float(seconds))
 
 
 def env_rank() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
-def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+def init_distributed(backend: str | None = None, timeout_s: Optional[float] = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process).  `timeout_s` (default
+    `DEFAULT_TIMEOUT_S` / TCX_DIST_TIMEOUT_S) bounds the rendezvous and every collective of the default group."""
     rank, world, local = env_rank()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -33,8 +50,36 @@ def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
             if os.environ.get("TCX_BENCH_SINGLE_DEVICE") != "1":
                 torch.cuda.set_device(local)
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())   # binds the RCCL communicator to this rank's GPU
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=dist_timeout(timeout_s), **kw)
     return rank, world, local
+
+
+class CollectiveHang(RuntimeError):
+    pass
+
+
+def guarded(fn: Callable, timeout_s: float, what: str, device: Optional[int] = None):
+    """Run `fn()` (an RCCL call that may block for ever: communicator bootstrap, a collective whose peer never arrives) on a
+    daemon thread and wait at most `timeout_s`.  Returns fn's result, re-raises its exception, or raises `CollectiveHang` and
+    ABANDONS the thread (it sits in native code with the GIL released; the caller must leave through `os._exit` in the end)."""
+    box = {}
+
+    def run():
+        try:
+            if device is not None:
+                torch.cuda.set_device(device)
+            box["out"] = fn()
+        except BaseException as e:                              # noqa: BLE001 — handed to the waiting thread
+            box["err"] = e
+
+    th = threading.Thread(target=run, name=f"tcx-guarded:{what}", daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        raise CollectiveHang(f"{what} did not return within {timeout_s:.0f} s")
+    if "err" in box:
+        raise box["err"]
+    return box.get("out")
 
 
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:

@@ -187,3 +187,68 @@ def random_state_dict(shapes: "Dict[str, Tuple[int, ...]]", seed: int = 0, dtype
             t = 0.02 * n
         sd[name] = t.to(dtype)
     return sd
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Host-independent random init.  `random_state_dict` draws from torch's CPU generator, whose normal transform goes
+# through libm / vectorised log-cos kernels: good within one host, not promised bit-identical across hosts.  The
+# reference-run fixtures at the product's default widths (tests/golden/make_golden.py default) store inputs and
+# outputs only and REGENERATE the ~0.5 B weights wherever the test runs, so they need a stream that is bit-exact
+# on every machine: integer hashing (splitmix64) + an Irwin-Hall sum of four 16-bit fields, i.e. integer arithmetic
+# and ONE float32 multiply per element.
+# ---------------------------------------------------------------------------------------------------------------
+_IH4_STD = 65536.0 * (1.0 / 3.0) ** 0.5            # std of the sum of four uniform 16-bit integers (to 8e-11 relative)
+
+
+def hashed_normal(shape, seed: int, stream: int, scale: float = 1.0) -> torch.Tensor:
+    """~N(0, scale^2) float32 tensor (Irwin-Hall n = 4: support +-3.46 sigma), bit-identical on every host."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    out = torch.empty(n, dtype=torch.float32)
+    i64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v                # two's-complement view of a 64-bit constant
+    lsr = lambda z, k: (z >> k) & ((1 << (64 - k)) - 1)                   # logical shift on int64 (wrap-around arithmetic = mod 2^64)
+    golden, c1, c2 = i64(0x9E3779B97F4A7C15), i64(0xBF58476D1CE4E5B9), i64(0x94D049BB133111EB)
+    base = i64(((((seed << 40) ^ (stream << 20)) * 0xD1B54A32D192ED03) + 0x9E3779B97F4A7C15) & ((1 << 64) - 1))
+    mul = float(np.float32(float(scale) / _IH4_STD))
+    step = 1 << 24
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        z = torch.arange(lo, hi, dtype=torch.int64) * golden + base
+        z = (z ^ lsr(z, 30)) * c1
+        z = (z ^ lsr(z, 27)) * c2
+        z = z ^ lsr(z, 31)
+        s = (z & 0xFFFF) + (lsr(z, 16) & 0xFFFF) + (lsr(z, 32) & 0xFFFF) + lsr(z, 48)
+        out[lo:hi] = (s - 131070).to(torch.float32) * mul
+    return out.reshape(tuple(shape))
+
+
+def hashed_state_dict(shapes: "Dict[str, Tuple[int, ...]]", seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """The recipe of `random_state_dict` on the host-independent stream, values rounded to bf16-representable float32
+    (the fixtures' models hold exactly these numbers in fp32 and in bf16)."""
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for stream, (name, shape) in enumerate(shapes.items()):
+        is_w = name.endswith("weight")
+        if len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            gain = 0.5 if ".linear." in name and ("norm1" in name or "norm2" in name or "norm_out" in name) else 1.0
+            if "conv_y" in name or "conv_b" in name:
+                gain = 0.3
+            t = hashed_normal(shape, seed, stream, gain / fan_in ** 0.5)
+        elif _is_norm_affine(name):
+            t = hashed_normal(shape, seed, stream, 0.1) + 1.0 if is_w else hashed_normal(shape, seed, stream, 0.05)
+        elif "conv_y.conv.bias" in name:
+            t = hashed_normal(shape, seed, stream, 0.1) + 1.0
+        else:
+            t = hashed_normal(shape, seed, stream, 0.02)
+        sd[name] = t.to(torch.bfloat16).float()
+    return sd
+
+
+def state_dict_digest(sd) -> str:
+    """sha256 over names, shapes and the bf16 bit patterns: what a fixture stores instead of the weights."""
+    import hashlib
+    h = hashlib.sha256()
+    for name, t in sd.items():
+        h.update(name.encode())
+        h.update(str(tuple(t.shape)).encode())
+        h.update(t.detach().to(torch.bfloat16).contiguous().view(torch.int16).numpy().tobytes())
+    return h.hexdigest()
