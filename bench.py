@@ -58,6 +58,9 @@ def parse(argv=None):
     ap.add_argument("--layers", type=int, default=42, help="(debug) fewer layers => NOT the benchmark config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="(debug) skip the VAE decode => NOT the benchmark config")
+    ap.add_argument("--alt-steps", type=int, default=5,
+                    help="after the timed steps: this many steps on each of the two other softmax paths the attention can take with "
+                         "other weights (bound unproven / exact running max everywhere); 0 = skip.  Never part of `value`.")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(child of the bench) time the oracle sample on the CPU, print its JSON")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="(CPU test hook) run only the launcher + rank plumbing on gloo, no GPU, no model")
@@ -455,6 +458,24 @@ def run_rank(args):
     lat = st.latents
     assert torch.isfinite(lat.float()).all(), "non-finite latents after the timed steps"
 
+    # ---- what the headline depends on.  The self-attention's fastest loop is taken when the q / k LayerNorm
+    # parameters PROVE the score bound (random-init: yes).  A real checkpoint may not: time the same steps on the two other paths,
+    # after the timed region, never part of `value`: (i) bound unproven = per-workgroup test + complement launch, (ii) the exact
+    # running-max kernel for every workgroup of self- and cross-attention = the cost if no row passed the test.
+    softmax_path = pipe.transformer.softmax_path_in_use()
+    alt = {}
+    if args.alt_steps > 0:
+        for name, path in (("unproven", "unproven"), ("exact_softmax", "exact")):
+            pipe.transformer.set_softmax_path(path)
+            one_step()                                          # warm-up of the other kernels
+            ops.attn_timing_start()
+            el, _ = timed(one_step, args.alt_steps)
+            at = ops.attn_timing_stop().get(64, {"n": 0, "ms": 0.0})
+            alt[name] = {"ms_per_step": 1e3 * el / args.alt_steps, "attn_avg_launch_ms": at["ms"] / max(at["n"], 1), "steps": args.alt_steps,
+                         "paths": pipe.transformer.softmax_path_in_use()}
+        pipe.transformer.set_softmax_path("auto")
+        assert torch.isfinite(st.latents.float()).all(), "non-finite latents after the alternative-path steps"
+
     decode_s = gather_s = 0.0
     frames_shape = None
     if not args.no_decode:
@@ -524,6 +545,19 @@ def run_rank(args):
                        "ranks": devices if world > 1 else [{"rank": 0, "device": torch.cuda.get_device_name(local), "device_count": torch.cuda.device_count()}],
                        "decode_ms": 1e3 * decode_s, "allgather_ms": 1e3 * gather_s,
                        "clip_seconds": clip_s, "timed_steps_seconds": elapsed, "init_seconds": t_init,
+                       "attn_bound_proven": softmax_path["self"] == "proven", "attn_softmax_path": softmax_path,
+                       "ms_per_step_unproven": alt.get("unproven", {}).get("ms_per_step"),
+                       "ms_per_step_exact_softmax": alt.get("exact_softmax", {}).get("ms_per_step"),
+                       "attn_tflops_unproven": (flop_per_launch / (alt["unproven"]["attn_avg_launch_ms"] * 1e-3) / 1e12
+                                                if alt.get("unproven", {}).get("attn_avg_launch_ms") else None),
+                       "attn_tflops_exact_softmax": (flop_per_launch / (alt["exact_softmax"]["attn_avg_launch_ms"] * 1e-3) / 1e12
+                                                     if alt.get("exact_softmax", {}).get("attn_avg_launch_ms") else None),
+                       "value_if_unproven": (world / (args.denoise_steps * alt["unproven"]["ms_per_step"] * 1e-3 + decode_s + gather_s)
+                                             if "unproven" in alt else None),
+                       "value_if_exact_softmax": (world / (args.denoise_steps * alt["exact_softmax"]["ms_per_step"] * 1e-3 + decode_s + gather_s)
+                                                  if "exact_softmax" in alt else None),
+                       "softmax_path_note": "value / ms_per_step use the path the loaded weights select (attn_softmax_path); the *_unproven and "
+                                            "*_exact_softmax figures bracket what other q/k-LayerNorm weights can cost, timed after the timed region",
                        "frames_out": frames_shape,
                        "transformer_mfma_frac": (None if fwd_flop is None else
                                                  2 * fwd_flop * (args.layers / 42) / step_s / 1e12 / PEAK_BF16_TFLOPS)},

@@ -730,8 +730,84 @@ def make_default():
               source="reference TrajCrafter_Pipeline.__call__ with every module .to(bfloat16), eager on the CPU, over tests/golden/diffusers_plain.py"))
 
 
+SIG_MODULES = {
+    "models.crosstransformer3d": "trajectorycrafter_amd.models.crosstransformer3d",
+    "models.autoencoder_magvit": "trajectorycrafter_amd.models.autoencoder_magvit",
+    "models.pipeline_trajectorycrafter": "trajectorycrafter_amd.models.pipeline_trajectorycrafter",
+}
+
+
+def describe_module(mod):
+    """{name: signature description} of everything DEFINED in `mod`: module-level functions and, per class, `__init__` and every
+    method / property the class body itself defines (inherited nn.Module / mixin members are not the module's surface).
+    A parameter is [name, kind, default repr | None]; shared by make_signatures (reference side) and tests/test_signatures.py
+    (mirror side), so both are described by the same code."""
+    def params(fn):
+        try:
+            sig = inspect.signature(fn)
+        except (TypeError, ValueError):
+            return None
+        return [[p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)] for p in sig.parameters.values()]
+
+    out = {"functions": {}, "classes": {}}
+    for name, obj in vars(mod).items():
+        if getattr(obj, "__module__", None) != mod.__name__ or name.startswith("_"):
+            continue
+        if inspect.isfunction(obj):
+            out["functions"][name] = params(obj)
+        elif inspect.isclass(obj):
+            members = {}
+            for mname, m in vars(obj).items():
+                if mname.startswith("_") and mname not in ("__init__", "__call__", "_decode", "_set_gradient_checkpointing",
+                                                           "_clear_fake_context_parallel_cache", "_get_t5_prompt_embeds", "_init_cross_inputs"):
+                    continue
+                if isinstance(m, (staticmethod, classmethod)):
+                    members[mname] = {"kind": type(m).__name__, "params": params(m.__func__)}
+                elif isinstance(m, property):
+                    members[mname] = {"kind": "property"}
+                elif inspect.isfunction(m) or (callable(m) and hasattr(m, "__wrapped__")):
+                    members[mname] = {"kind": "method", "params": params(inspect.unwrap(m))}
+            out["classes"][name] = {"bases": [b.__name__ for b in obj.__mro__[1:] if b.__module__ not in ("builtins",)][:4], "members": members}
+    return out
+
+
+def make_signatures():
+    """signatures.json: the call surface of the reference's three hot-path modules as `inspect` sees it —
+    every function / class / method name with parameter names, kinds and defaults — plus the state-dict key -> shape lists of the
+    5B transformer and the default VAE built from the REFERENCE's constructors (meta device).  tests/test_signatures.py compares
+    the mirrors in trajectorycrafter_amd/models against it mechanically."""
+    if not os.path.isdir(REF):
+        raise SystemExit("make_golden.py needs /root/reference (build container only)")
+    install_scaffolding(plain=True)
+    sys.path.insert(0, REF)
+    import importlib
+    import json
+    import warnings
+    warnings.filterwarnings("ignore")
+    out = {"source": "inspect.signature over the reference's models/{crosstransformer3d,autoencoder_magvit,pipeline_trajectorycrafter}.py "
+                     "(imported in the build container over tests/golden/diffusers_plain.py)", "modules": {}}
+    for ref_name in SIG_MODULES:
+        out["modules"][ref_name] = describe_module(importlib.import_module(ref_name))
+    from models.crosstransformer3d import CrossTransformer3DModel
+    from models.autoencoder_magvit import AutoencoderKLCogVideoX
+    with torch.device("meta"):
+        tr = CrossTransformer3DModel(**iw.TRANSFORMER_5B)
+        vae = AutoencoderKLCogVideoX()
+    out["state_dict"] = {"CrossTransformer3DModel(5B)": {k: list(v.shape) for k, v in tr.state_dict().items()},
+                         "AutoencoderKLCogVideoX()": {k: list(v.shape) for k, v in vae.state_dict().items()}}
+    out["config"] = {"CrossTransformer3DModel(5B)": {k: (list(v) if isinstance(v, tuple) else v) for k, v in dict(tr.config).items()},
+                     "AutoencoderKLCogVideoX()": {k: (list(v) if isinstance(v, tuple) else v) for k, v in dict(vae.config).items()}}
+    with open(os.path.join(HERE, "signatures.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    n = sum(len(c["members"]) for m in out["modules"].values() for c in m["classes"].values()) + sum(len(m["functions"]) for m in out["modules"].values())
+    print(f"wrote signatures.json: {n} callables, {len(out['state_dict']['CrossTransformer3DModel(5B)'])} + "
+          f"{len(out['state_dict']['AutoencoderKLCogVideoX()'])} state-dict keys, {os.path.getsize(os.path.join(HERE, 'signatures.json')) / 1e3:.0f} kB")
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["default"]:
+    if sys.argv[1:] == ["signatures"]:
+        make_signatures()
+    elif sys.argv[1:] == ["default"]:
         make_default()                                     # own process: the stand-in generation is fixed when the reference is imported
     elif sys.argv[1:] == ["tiled"]:
         make_tiled()

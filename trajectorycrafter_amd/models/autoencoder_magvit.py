@@ -83,8 +83,47 @@ def _pad_channels(x: torch.Tensor, mult: int = 8) -> torch.Tensor:
     return x if c % mult == 0 else torch.nn.functional.pad(x, (0, mult - c % mult))
 
 
+def _to_cl(x: torch.Tensor) -> torch.Tensor:
+    """The reference's [N,C,T,H,W] -> this module's channels-last [N,T,H,W,C] (tcx_ncthw_to_cl)."""
+    if x.dim() != 5:
+        raise ValueError(f"expected a [N, C, T, H, W] tensor, got {tuple(x.shape)}")
+    return ops.ncthw_to_cl(x, 1.0)
+
+
+def _from_cl(y: torch.Tensor) -> torch.Tensor:
+    return y.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def _no_temb(temb, who: str) -> None:
+    if temb is not None:
+        raise NotImplementedError(f"{who}: the VAE builds its blocks with temb_channels=0 and never passes `temb` (reference :784,795,"
+                                  ":934,944); a time embedding is not built on this path")
+
+
+# The sub-modules below carry two entry points.  `forward_cl(...)` on channels-last activations is what the composed
+# encoder / decoder run.  `forward(...)` has the REFERENCE's signature and layout ([N,C,T,H,W] in and out) and runs the same HIP
+# kernels behind a layout conversion, so code written against the reference's sub-modules (`resnet(x, temb, zq)`,
+# `norm(f, zq)`, `conv(x)`) works; tests/test_signatures.py compares the signatures with the reference's mechanically.
 class CogVideoXSafeConv3d(nn.Conv3d):
-    """reference :41-73.  Parameter container; the >2 GiB chunking is unnecessary (no cuDNN workspace)."""
+    """reference :41-73.  The >2 GiB chunking is unnecessary (no cuDNN workspace)."""
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        """reference :61-73: the module's own convolution of an NCTHW tensor — no causal context, the module's `padding`
+        spatially, none in time beyond it (a "valid" temporal convolution: the first kT-1 frames serve as context)."""
+        kt, kh, kw = self.kernel_size
+        if self.stride != (1, 1, 1) or self.dilation != (1, 1, 1) or self.padding[0] != 0 or self.groups != 1:
+            raise NotImplementedError("CogVideoXSafeConv3d.forward: stride / dilation 1, no temporal padding, groups 1 on this path")
+        if not hasattr(self, "_wcl"):
+            self._wcl = _PermutedWeight()
+        x = _pad_channels(_to_cl(input))
+        N, T, H, W, _ = x.shape
+        if T < kt:
+            raise ValueError(f"CogVideoXSafeConv3d.forward: {T} frames for a temporal kernel of {kt}")
+        ph, pw = self.padding[1], self.padding[2]
+        cache = x[:, :kt - 1].contiguous() if kt > 1 else None
+        y = ops.conv3d_cl(x[:, kt - 1:].contiguous(), self._wcl.get(self.weight), self.bias, cache=cache, pad=(ph, pw),
+                          out_hw=(H + 2 * ph - kh + 1, W + 2 * pw - kw + 1))
+        return _from_cl(y)
 
     def forward_cl(self, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
         if not hasattr(self, "_wcl"):
@@ -110,6 +149,22 @@ class CogVideoXCausalConv3d(nn.Module):
     def _clear_fake_context_parallel_cache(self):
         self.conv_cache = None
 
+    def fake_context_parallel_forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        """reference :135-143: the NCTHW input with its causal context in front — the cached last kT-1 frames of the previous
+        chunk, or frame 0 repeated.  (The HIP conv never builds this tensor: the context is address arithmetic in its gather.)"""
+        kt = self.time_kernel_size
+        if kt > 1:
+            if self.conv_cache is not None:
+                ctx = self.conv_cache[..., :inputs.shape[1]].permute(0, 4, 1, 2, 3).to(inputs.dtype)
+                inputs = torch.cat([ctx, inputs], dim=2)
+            else:
+                inputs = torch.cat([inputs[:, :, :1]] * (kt - 1) + [inputs], dim=2)
+        return inputs
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        """reference :149-163 on its NCTHW layout; updates `conv_cache` like the reference."""
+        return _from_cl(self.forward_cl(_to_cl(inputs)))
+
     def forward_cl(self, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
         kt = self.time_kernel_size
         x = _pad_channels(x)
@@ -132,6 +187,10 @@ class CogVideoXSpatialNorm3D(nn.Module):
         self.conv_y = CogVideoXCausalConv3d(zq_channels, f_channels, kernel_size=1, stride=1)
         self.conv_b = CogVideoXCausalConv3d(zq_channels, f_channels, kernel_size=1, stride=1)
         self.groups = groups
+
+    def forward(self, f: torch.Tensor, zq: torch.Tensor) -> torch.Tensor:
+        """reference :183-212 on NCTHW tensors: `norm_layer(f) * conv_y(zq') + conv_b(zq')`, zq resized to f (no activation)."""
+        return _from_cl(self.forward_cl(_to_cl(f), _to_cl(zq), silu=False))
 
     def forward_cl(self, f: torch.Tensor, zq: torch.Tensor, silu: bool = True) -> torch.Tensor:
         T, Tz = f.shape[1], zq.shape[1]
@@ -174,6 +233,11 @@ class CogVideoXResnetBlock3D(nn.Module):
             else:
                 self.conv_shortcut = CogVideoXSafeConv3d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
 
+    def forward(self, inputs: torch.Tensor, temb: Optional[torch.Tensor] = None, zq: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """reference :320-355 on NCTHW tensors (`zq` given for the decoder's SpatialNorm blocks, None for the encoder's)."""
+        _no_temb(temb, "CogVideoXResnetBlock3D.forward")
+        return _from_cl(self.forward_cl(_to_cl(inputs), None if zq is None else _to_cl(zq)))
+
     def forward_cl(self, x: torch.Tensor, zq: Optional[torch.Tensor] = None) -> torch.Tensor:
         h = self.norm1.forward_cl(x, zq) if zq is not None else _groupnorm_silu(self.norm1, x)       # :328-333
         h = self.conv1.forward_cl(h)                                                                 # :334
@@ -192,6 +256,10 @@ class CogVideoXUpsample3D(nn.Module):
         self.compress_time = compress_time
         self._wcl = _PermutedWeight()
 
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        """diffusers `CogVideoXUpsample3D.forward` on an NCTHW tensor."""
+        return _from_cl(self.forward_cl(_to_cl(inputs)))
+
     def forward_cl(self, x: torch.Tensor) -> torch.Tensor:
         tmap = _dev_map(upsample_t_map(x.shape[1], self.compress_time), x.device)
         return ops.conv3d_cl(x, self._wcl.get(self.conv.weight), self.conv.bias, ups=1, t_map=tmap)
@@ -207,6 +275,10 @@ class CogVideoXDownsample3D(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding)
         self.compress_time = compress_time
         self._wcl = _PermutedWeight()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """diffusers `CogVideoXDownsample3D.forward` on an NCTHW tensor."""
+        return _from_cl(self.forward_cl(_to_cl(x)))
 
     def forward_cl(self, x: torch.Tensor) -> torch.Tensor:
         if self.compress_time and x.shape[1] > 1:
@@ -231,6 +303,11 @@ class CogVideoXDownBlock3D(nn.Module):
             self.downsamplers = nn.ModuleList([CogVideoXDownsample3D(out_channels, out_channels, padding=downsample_padding,
                                                                      compress_time=compress_time)])
 
+    def forward(self, hidden_states: torch.Tensor, temb: Optional[torch.Tensor] = None, zq: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """reference :436-464 on NCTHW tensors (`zq` is accepted and unused by the encoder's blocks, as in the reference)."""
+        _no_temb(temb, "CogVideoXDownBlock3D.forward")
+        return _from_cl(self.forward_cl(_to_cl(hidden_states)))
+
     def forward_cl(self, x):
         for r in self.resnets:
             x = r.forward_cl(x, None)
@@ -250,6 +327,11 @@ class CogVideoXMidBlock3D(nn.Module):
         self.resnets = nn.ModuleList([
             CogVideoXResnetBlock3D(in_channels, in_channels, dropout, temb_channels, resnet_groups, resnet_eps, resnet_act_fn,
                                    spatial_norm_dim=spatial_norm_dim, pad_mode=pad_mode) for _ in range(num_layers)])
+
+    def forward(self, hidden_states: torch.Tensor, temb: Optional[torch.Tensor] = None, zq: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """reference :524-548 on NCTHW tensors."""
+        _no_temb(temb, "CogVideoXMidBlock3D.forward")
+        return _from_cl(self.forward_cl(_to_cl(hidden_states), None if zq is None else _to_cl(zq)))
 
     def forward_cl(self, x, zq=None):
         for r in self.resnets:
@@ -272,6 +354,11 @@ class CogVideoXUpBlock3D(nn.Module):
         if add_upsample:
             self.upsamplers = nn.ModuleList([CogVideoXUpsample3D(out_channels, out_channels, padding=upsample_padding,
                                                                  compress_time=compress_time)])
+
+    def forward(self, hidden_states: torch.Tensor, temb: Optional[torch.Tensor] = None, zq: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """reference :631-660 on NCTHW tensors."""
+        _no_temb(temb, "CogVideoXUpBlock3D.forward")
+        return _from_cl(self.forward_cl(_to_cl(hidden_states), None if zq is None else _to_cl(zq)))
 
     def forward_cl(self, x, zq):
         for r in self.resnets:

@@ -62,6 +62,27 @@ def get_3d_rotary_pos_embed(embed_dim: int, crops_coords, grid_size, temporal_si
     return freqs.cos().contiguous(), freqs.sin().contiguous()
 
 
+def retrieve_timesteps(scheduler, num_inference_steps: Optional[int] = None, device=None, timesteps: Optional[List[int]] = None,
+                       sigmas: Optional[List[float]] = None, **kwargs):
+    """reference :62-124 (a diffusers helper the reference module carries but its `__call__` never uses, :846): let the scheduler
+    build its schedule — from a step count, or from caller-given `timesteps` / `sigmas` when its `set_timesteps` takes them — and
+    return `(scheduler.timesteps, number of steps)`."""
+    import inspect
+    if timesteps is not None and sigmas is not None:
+        raise ValueError("Only one of `timesteps` or `sigmas` can be passed. Please choose one to set custom values")
+    accepted = set(inspect.signature(scheduler.set_timesteps).parameters)
+    for name, custom in (("timesteps", timesteps), ("sigmas", sigmas)):
+        if custom is None:
+            continue
+        if name not in accepted:
+            raise ValueError(f"The current scheduler class {scheduler.__class__}'s `set_timesteps` does not support custom {name} "
+                             "schedules. Please check whether you are using the correct scheduler.")
+        scheduler.set_timesteps(device=device, **{name: custom}, **kwargs)
+        return scheduler.timesteps, len(scheduler.timesteps)
+    scheduler.set_timesteps(num_inference_steps, device=device, **kwargs)
+    return scheduler.timesteps, num_inference_steps
+
+
 def resize_mask(mask, latent, process_first_frame_only=True):
     """reference :127-160."""
     latent_size = latent.size()
@@ -259,31 +280,42 @@ class TrajCrafter_Pipeline:
                                  f"{negative_prompt_embeds.shape}.")
 
     def prepare_latents(self, batch_size, num_channels_latents, height, width, video_length, dtype, device, generator,
-                        latents=None, video=None, timestep=None, is_strength_max=True):
-        """reference :383-457.  strength == 1: pure noise * init_noise_sigma; strength < 1 (and no `latents=`): the VAE-encoded
-        (posterior SAMPLE, global RNG, x scaling_factor) preprocessed `video` noised to the first timestep of the shortened loop
-        (`scheduler.add_noise`, :431-436).  -> (latents, noise)."""
+                        latents=None, video=None, timestep=None, is_strength_max=True, return_noise=False,
+                        return_video_latents=False):
+        """reference :383-457, same arguments, same return: the tuple `(latents,) [+ (noise,)] [+ (video_latents,)]`.
+        strength == 1: pure noise * init_noise_sigma; strength < 1 (and no `latents=`): the VAE-encoded preprocessed `video` —
+        one posterior SAMPLE per batch item, drawn item by item from the global RNG like the reference's loop (:414-421), times
+        scaling_factor — noised to the first timestep of the shortened loop (`scheduler.add_noise`, :431-436)."""
         shape = (batch_size, (video_length - 1) // self.vae_scale_factor_temporal + 1, num_channels_latents,
                  height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial)
         if isinstance(generator, list) and len(generator) != batch_size:
             raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective "
-                             f"batch size of {batch_size}.")
+                             f"batch size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        video_latents = None
+        if return_video_latents or (latents is None and not is_strength_max):
+            if video is None:
+                raise ValueError("`strength` < 1 (or return_video_latents=True) starts from the encoded `video`: pass `video=`")
+            video = video.to(device=device, dtype=dtype)
+            parts = [self.vae.encode(video[i:i + 1])[0].sample() for i in range(video.shape[0])]          # :414-421, bs = 1
+            vl = torch.cat(parts, dim=0) * self.vae.config.scaling_factor
+            video_latents = vl.repeat(batch_size // vl.shape[0], 1, 1, 1, 1).to(device=device, dtype=dtype).permute(0, 2, 1, 3, 4)
         if latents is None:
-            video_latents = None
-            if not is_strength_max:
-                if video is None:
-                    raise ValueError("`strength` < 1 starts from the encoded `video`: pass `video=` (or `latents=`)")
-                vl = self.vae.encode(video.to(device=device, dtype=dtype))[0].sample() * self.vae.config.scaling_factor   # :410-421
-                video_latents = vl.repeat(batch_size // vl.shape[0], 1, 1, 1, 1).to(dtype).permute(0, 2, 1, 3, 4)
-            gdev = generator.device if generator is not None else device
+            gdev = generator.device if generator is not None and not isinstance(generator, list) else device
             noise = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)     # randn_tensor
-            if video_latents is not None:
-                return self.scheduler.add_noise(video_latents, noise, timestep).to(dtype), noise     # :431-436, no init sigma (:438-442)
+            # pure noise is scaled by the scheduler's init sigma; image + noise is not (:438-442)
+            latents = noise * self.scheduler.init_noise_sigma if is_strength_max else \
+                self.scheduler.add_noise(video_latents, noise, timestep).to(dtype)
         else:
             if tuple(latents.shape) != shape:
                 raise ValueError(f"`latents` has shape {tuple(latents.shape)}, expected {shape}")
             noise = latents.to(device=device, dtype=dtype)
-        return noise * self.scheduler.init_noise_sigma, noise
+            latents = noise * self.scheduler.init_noise_sigma
+        outputs = (latents,)
+        if return_noise:
+            outputs += (noise,)
+        if return_video_latents:
+            outputs += (video_latents,)
+        return outputs
 
     def _prepare_rotary_positional_embeddings(self, height: int, width: int, num_frames: int, device):
         """reference :616-649."""
@@ -491,6 +523,8 @@ class TrajCrafter_Pipeline:
         if not 0.0 < strength <= 1.0:
             raise ValueError(f"`strength` must be in (0, 1], got {strength}")
         num_videos_per_prompt = 1
+        if hasattr(self.transformer, "clear_cross_kv_cache"):
+            self.transformer.clear_cross_kv_cache()               # opt-in K / V reuse (model.cache_cross_kv) never outlives a clip
         self.check_inputs(prompt, height, width, negative_prompt, list(callback_on_step_end_tensor_inputs), prompt_embeds,
                           negative_prompt_embeds)
         self._guidance_scale = guidance_scale
@@ -539,9 +573,9 @@ class TrajCrafter_Pipeline:
         init_video = None
         if strength != 1 and latents is None and video is not None:
             init_video = self._preprocess(video.to(device), height, width)                              # :863-871
-        latents, _ = self.prepare_latents(batch_size * num_videos_per_prompt, num_channels_latents, height, width,
-                                          video_length, BF16, device, generator, latents, video=init_video,
-                                          timestep=timesteps[:1], is_strength_max=strength == 1)
+        latents = self.prepare_latents(batch_size * num_videos_per_prompt, num_channels_latents, height, width,
+                                       video_length, BF16, device, generator, latents, video=init_video,
+                                       timestep=timesteps[:1], is_strength_max=strength == 1)[0]
         latents = latents.contiguous()
         if inpaint_latents.shape[:2] != (rep * batch_size, latents.shape[1]) or inpaint_latents.shape[3:] != latents.shape[3:]:
             raise ValueError(f"inpaint_latents {tuple(inpaint_latents.shape)} does not match latents {tuple(latents.shape)}")
