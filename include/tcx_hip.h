@@ -63,14 +63,6 @@ int tcx_device_info(int device, int32_t out[4]);
  * kernel then skips the per-workgroup test and the launch of the exact kernel on the (empty) complement: -63 us per call at the
  * product shape.  A false guarantee cannot corrupt memory, but rows whose scores sit more than ~120 below the bound underflow. */
 #define TCX_ATTN_BOUND_PROVEN 2
-/* TCX_ATTN_BODY_16X16X32 (only effective with TCX_ATTN_BOUND_PROVEN, D = 64, bf16 output; ignored otherwise): run the bound-centred
- * loop on v_mfma_f32_16x16x32_bf16 tiles instead of 32x32x16 (same algorithm, same rounding points, other MFMA shape and lane
- * layout; results agree to fp32 summation order).  Which body the product uses is decided by measurement. */
-#define TCX_ATTN_BODY_16X16X32 4
-/* TCX_ATTN_BODY_4WAVE (same conditions; takes precedence over TCX_ATTN_BODY_16X16X32): 256-thread workgroups, one wave per SIMD with
- * the whole register file, each wave two 32-row query blocks that share every K / V fragment read; uncentred softmax (P = exp2(S),
- * valid because the proven bound keeps |S| < 60), row sums on the matrix pipe.  Same rounding points (one bf16 rounding of P). */
-#define TCX_ATTN_BODY_4WAVE 8
 int tcx_attn_fwd(const void* q, const void* k, const void* v, void* o,
                  int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t D,
                  int64_t q_stride_b, int64_t q_stride_s, int64_t q_stride_h,

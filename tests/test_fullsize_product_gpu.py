@@ -111,13 +111,6 @@ def test_self_attention_shipped_path_fullsize(ops, gpu, rotary):
     # (2b) TCX_ATTN_BOUND_PROVEN (what the model passes when the LayerNorm parameters prove M < 60): no per-workgroup test, no
     #      complement launch -> the same bits
     assert torch.equal(ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True), o)
-    assert torch.equal(ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=False), o)
-    # ... and the optional 16x16x32 body (its own full-size test below): same rows, same bounds
-    o16 = ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=True)
-    for h in heads:
-        for b in range(B):
-            err = (o16[b, rows, h].float() - _softmax2_rows(q[b, rows, h], k[b, :, h], v[b, :, h])).abs()
-            assert float(err.max()) < 2e-3 and float(err.mean()) < 2.5e-4
 
     # (3) one workgroup forced over the predicate: rows 1024..1030 of (b=1, h=5) scaled x6 -> M ~ 70 >= 60 for q-block 4
     #     (rows 1024..1279).  That workgroup must be computed by the complement launch = the exact-tracking kernel:
@@ -177,38 +170,6 @@ def test_self_attention_tail_split_fullsize(ops, gpu):
     assert torch.isfinite(c.float()).all()
     # repeatable (parts are added in a fixed order)
     assert torch.equal(c, ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq))
-
-
-@pytest.mark.parametrize("body", [True, 4])
-def test_self_attention_body_16x16x32_fullsize(ops, gpu, rotary, body):
-    """body = True: the 16x16x32 MFMA body (TCX_ATTN_BODY_16X16X32); body = 4: the 4-wave x 64-row body (TCX_ATTN_BODY_4WAVE) — each through the product's call chain at [2, 17776, 48, 64] on the fused-QKV
-    layout: LN + RoPE (q pre-scaled, k_sqmax) -> attn_fwd(bound_proven, body16) with the tail split, against fp32 on sampled rows
-    (same bounds as the shipped body: max < 2e-3, mean < 2.5e-4) and against the 32x32x16 body on EVERY element (both round each
-    probability once: |diff| <= 1 bf16 ulp + 2e-4); single-pass (no split) likewise; repeatable."""
-    cos, sin = rotary
-    g = torch.Generator(device=gpu).manual_seed(16)
-    qkv = torch.randn(B, S, 3 * H * D, device=gpu, dtype=BF, generator=g)
-    q, k, v = (t.view(B, S, H, D) for t in qkv.chunk(3, -1))
-    gq, bq, gk, bk = (torch.randn(D, device=gpu, dtype=BF, generator=g) * s_ + o_ for s_, o_ in ((0.1, 1.0), (0.05, 0.0), (0.1, 1.0), (0.05, 0.0)))
-    ksq = ops.qk_layernorm_rope(q, k, gq, bq, gk, bk, cos, sin, TEXT, 1e-6, q_scale=D ** -0.5 * LOG2E, want_k_sqmax=True)
-    o32 = ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=False)
-    o16 = ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=body)
-    assert torch.isfinite(o16.float()).all()
-    d = (o16.float() - o32.float()).abs()
-    assert bool((d <= o32.float().abs() * 2.0 ** -7 + 2e-4).all()), float(d.max())      # 17 776 keys average the P-rounding flips out
-    rows = torch.tensor([0, 1, 15, 16, 31, 32, 225, 226, 255, 256, 4097, 8888, 17000, 17519, 17520, 17775], device=gpu)
-    emax = emean = 0.0
-    for h in (0, 17, 47):
-        for b in range(B):
-            ref = _softmax2_rows(q[b, rows, h], k[b, :, h], v[b, :, h])
-            err = (o16[b, rows, h].float() - ref).abs()
-            emax, emean = max(emax, float(err.max())), max(emean, float(err.mean()))
-    print(f"self-attention optional body {body}, sampled rows: max err {emax:.3e}, worst mean err {emean:.3e}; max |16 - 32 body| {float(d.max()):.3e}")
-    assert emax < 2e-3 and emean < 2.5e-4
-    o16s = ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=body, split_tail=False)
-    ds = (o16s.float() - o16.float()).abs()
-    assert bool((ds <= o16.float().abs() * 2.0 ** -7 + 1e-4).all()), float(ds.max())       # split parts: fp32 summation order only
-    assert torch.equal(o16, ops.attn_fwd(q, k, v, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=body))
 
 
 def test_cross_attention_shipped_path_fullsize(ops, gpu):

@@ -75,8 +75,6 @@ def test_attention_random_shapes(ops, D, B, H, Sq, Sk, fused_layout):
         if M * 1.002 + 1e-3 < 60:
             outs["proven"] = ops.attn_fwd(dq, dk, dv, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True)
             outs["proven, single pass"] = ops.attn_fwd(dq, dk, dv, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, split_tail=False)
-            outs["16x16x32 body"] = ops.attn_fwd(dq, dk, dv, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=True)
-            outs["4-wave body"] = ops.attn_fwd(dq, dk, dv, 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=4)
     else:
         outs["bound"] = ops.attn_fwd(dq, dk, dv, 1.0, log2_scores=True, k_sqmax=ksq)
     for name, o in outs.items():

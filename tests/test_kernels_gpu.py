@@ -116,41 +116,6 @@ def test_attn_fwd_log2_scores_fast_path(ops, B, H, Sq, Sk, D):
     assert_bf16_close(o16b, ref, extra=bound)
 
 
-@pytest.mark.parametrize("B,H,Sq,Sk", [(1, 2, 300, 333), (2, 3, 513, 64), (1, 1, 1, 1), (1, 2, 70, 129), (1, 1, 256, 2048), (1, 1, 40, 128),
-                                       (1, 2, 33, 100), (1, 1, 64, 300), (1, 1, 64, 449), (1, 1, 31, 63), (1, 1, 17, 65)])
-@pytest.mark.parametrize("body", [True, 4])
-def test_attn_fwd_body_16x16x32(ops, B, H, Sq, Sk, body):
-    """body = True: TCX_ATTN_BODY_16X16X32; body = 4: TCX_ATTN_BODY_4WAVE (4 waves x 64 rows, uncentred P = exp2(S), row sums on the
-    matrix pipe).  TCX_ATTN_BODY_16X16X32: the bound-centred D = 64 loop on v_mfma_f32_16x16x32_bf16 tiles (other lane layout, other V image
-    swizzle, key-pair P operands).  Same contract and tolerance as the 32x32x16 body: vs the oracle (dr.sdpa_log2) within one bf16
-    ulp + the P-rounding bound, and vs the 32x32x16 body within the same (both round every probability once; they differ by fp32
-    summation order only).  Key counts cover 1, 2, 3, 5, 8 and 32 tiles and ragged last tiles; Sq covers ragged query blocks."""
-    D = 64
-    g = torch.Generator().manual_seed(7 * Sq + Sk)
-    q, k, v = (bf(torch.randn(B, s, H, D, generator=g)) for s in (Sq, Sk, Sk))
-    q = bf(q.float() * (D ** -0.5 * 1.4426950408889634))
-    qt, kt, vt = q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)
-    ref = dr.sdpa_log2(Prec("bf16"), qt, kt, vt).transpose(1, 2).contiguous()
-    pr = torch.softmax(torch.matmul(qt, kt.transpose(-1, -2)) * math.log(2.0), dim=-1)
-    bound = 3 * (2.0 ** -9) * torch.matmul(pr, vt.abs()).transpose(1, 2).contiguous()
-    ksq = dev((k.float() ** 2).sum(-1).amax(1).contiguous())
-    o32 = ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=False)
-    o16 = ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=body)
-    assert o16.dtype == BF
-    # vs the oracle: every element within one bf16 ulp + the P-rounding bound; mean error no worse than the 32x32x16 body's
-    assert_bf16_close(o16, ref, extra=bound, mean_frac=0.5)
-    e16, e32 = float((o16.float().cpu() - ref).abs().mean()), float((o32.float().cpu() - ref).abs().mean())
-    assert e16 <= 1.05 * e32 + 1e-6, (e16, e32)
-    # vs the 32x32x16 body: the exponent origin M = |q| max|k| is summed in another lane order (last-bit differences), so a
-    # probability near a bf16 tie may round the other way: within one output ulp + the same P-rounding bound
-    d = (o16.float() - o32.float()).abs().cpu()
-    assert bool((d <= o32.float().abs().cpu() * 2.0 ** -7 + 1e-5 + bound).all()), float(d.max())
-    assert torch.equal(o16, ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, log2_scores=True, k_sqmax=ksq, bound_proven=True, body16=body))
-    # without the proven flag the request is ignored (the per-workgroup predicate lives in the 32x32x16 kernels only)
-    assert torch.equal(ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, log2_scores=True, k_sqmax=ksq, body16=body),
-                       ops.attn_fwd(dev(q), dev(k), dev(v), 1.0, log2_scores=True, k_sqmax=ksq, body16=False))
-
-
 def test_attn_fwd_fast_path_forced_recentre(ops):
     """Rule 26 for the FAST path: scores that start very negative (first-tile re-centre with delta < 0), a
     late spike above the deferral threshold for some rows only, and a ragged last tile."""

@@ -3,6 +3,11 @@ process (cdna_hip_programming.md rule 24), random data, the product's flags (bou
 usage: python tools/attn_body_bench.py [iters] [rounds]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import inspect as _inspect
+from trajectorycrafter_amd import ops as _ops
+if "body16" not in _inspect.signature(_ops.attn_fwd).parameters:
+    raise SystemExit("this tool compares attention bodies that live in tools/exp/attn_gemm_experiments.patch: run it in the patched copy: "
+                     "bash -c '. tools/exp/with_experiments.sh && python3 tools/attn_body_bench.py'")
 import torch
 from trajectorycrafter_amd import ops
 _fused = "--fused" in sys.argv

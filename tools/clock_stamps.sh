@@ -3,6 +3,7 @@
 # the main loop and print them for a few workgroups; clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6),
 # after >= 2 s of back-to-back launches on random data.  Usage on the GPU box:  bash tools/clock_stamps.sh <tag>
 # Writes gpurun_out/<tag>_clock.json (+ the raw stamp lines in gpurun_out/<tag>_clock_raw.log).
+. "$(dirname "${BASH_SOURCE[0]}")/exp/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 tag=${1:-r3}
 R=$GRAFT_REPO_ROOT
 cd $R/trajectorycrafter_amd/csrc

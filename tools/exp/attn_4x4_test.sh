@@ -1,4 +1,5 @@
 # parity + A/B of the 4x4x4 row-sum build of the fine loop
+. "$(dirname "${BASH_SOURCE[0]}")/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 R=$GRAFT_REPO_ROOT
 cd $R/trajectorycrafter_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -w -I. -DTCX_ATTN_FINE_SUM_4X4 -x hip -c attn_fwd.hip -o /tmp/attn_4.o || exit 1

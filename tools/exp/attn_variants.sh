@@ -1,5 +1,6 @@
 # A/B of compile-time variants of attn_fwd.hip on one box: each variant = extra -D flags; builds a private libtcx copy per variant and
 # runs tools/attn_body_bench.py for them in alternation (two rounds).  usage: bash tools/exp/attn_variants.sh "-DFLAG_A" "-DFLAG_B" ...
+. "$(dirname "${BASH_SOURCE[0]}")/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 R=$GRAFT_REPO_ROOT
 cd $R/trajectorycrafter_amd/csrc
 i=0

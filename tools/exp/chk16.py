@@ -1,5 +1,10 @@
 import torch, math, sys
 sys.path.insert(0,'/root/repo')
+import inspect as _inspect
+from trajectorycrafter_amd import ops as _ops
+if "body16" not in _inspect.signature(_ops.attn_fwd).parameters:
+    raise SystemExit("this tool compares attention bodies that live in tools/exp/attn_gemm_experiments.patch: run it in the patched copy: "
+                     "bash -c '. tools/exp/with_experiments.sh && python3 tools/exp/chk16.py'")
 from trajectorycrafter_amd import ops
 B,S,H,D=1,1000,2,64
 g=torch.Generator(device='cuda').manual_seed(0)

@@ -1,5 +1,6 @@
 # A/B of the D = 128 (cross-attention) loop: K fragments of the next 16-key step requested into the same registers right behind the
 # QK^T MFMAs (default build) vs read at the point of use (-DTCX_EXP_NOKPREF); parity tests on the default build first
+. "$(dirname "${BASH_SOURCE[0]}")/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 cd $GRAFT_REPO_ROOT
 python3 -m pytest tests/test_kernels_gpu.py tests/test_fullsize_product_gpu.py -m gpu -x -q -k "cross or attn or attention" 2>&1 | tail -1
 cd trajectorycrafter_amd/csrc

@@ -1,4 +1,5 @@
 # A/B of compile-time variants of norm.hip on one box (alternating runs of tools/microbench.py rows).  usage: bash tools/exp/norm_variants.sh "-DFLAG" ...
+. "$(dirname "${BASH_SOURCE[0]}")/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 R=$GRAFT_REPO_ROOT
 cd $R/trajectorycrafter_amd/csrc
 i=0

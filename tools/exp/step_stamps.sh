@@ -1,4 +1,5 @@
 # in-model stamps of the two attention bodies: cycles + clock inside the full denoising step (tools/step_ab.py under a -DTCX_ATTN_STAMP build)
+. "$(dirname "${BASH_SOURCE[0]}")/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 R=$GRAFT_REPO_ROOT
 cd $R/trajectorycrafter_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -w -I. -DTCX_ATTN_STAMP -x hip -c attn_fwd.hip -o /tmp/attn_clk.o || exit 1

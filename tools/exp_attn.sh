@@ -1,6 +1,7 @@
 # Timing-only ablation builds of the self-attention kernel (results are wrong by construction; never shipped).
 # Each -DTCX_EXP_* removes one ingredient of the loop: global loads, LDS writes, the barrier, the exponentials,
 # the LDS fragment reads, the PV MFMAs.  Usage on the GPU box:  bash tools/exp_attn.sh
+. "$(dirname "${BASH_SOURCE[0]}")/exp/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 cd $GRAFT_REPO_ROOT/trajectorycrafter_amd/csrc
 BASE="-DTCX_EXP_NOLOAD -DTCX_EXP_NOWRITE -DTCX_EXP_NOBARRIER"
 i=0

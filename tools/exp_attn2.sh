@@ -1,4 +1,5 @@
 # A/B of attention build variants on one box.  Usage on the GPU box: bash tools/exp_attn2.sh
+. "$(dirname "${BASH_SOURCE[0]}")/exp/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 cd $GRAFT_REPO_ROOT/trajectorycrafter_amd/csrc
 i=0
 for extra in "" "-DTCX_EXP_DIRECT_OSTORE" "" "-DTCX_EXP_DIRECT_OSTORE"; do

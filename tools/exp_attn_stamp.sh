@@ -1,6 +1,7 @@
 # In-kernel cycle stamps (s_memtime) of the shipped attention loop: loop total, LDS-write segment, barrier wait, for
 # waves 0 and 7 of two workgroups.  Patches a COPY of attn_fwd.hip; timing-only build.  Usage on the GPU box:
 #   bash tools/exp_attn_stamp.sh
+. "$(dirname "${BASH_SOURCE[0]}")/exp/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 cd $GRAFT_REPO_ROOT/trajectorycrafter_amd/csrc
 python3 - <<'PY'
 s = open("attn_fwd.hip").read()

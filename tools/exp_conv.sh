@@ -1,5 +1,6 @@
 # Timing experiments on the conv_mfma kernel (some variants are deliberately wrong: timing only, never shipped).
 # Usage on the GPU box: bash tools/exp_conv.sh "<flags of variant 1>" "<flags of variant 2>" ...   ("" = shipped)
+. "$(dirname "${BASH_SOURCE[0]}")/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 cd $GRAFT_REPO_ROOT/trajectorycrafter_amd/csrc
 i=0
 for extra in "$@"; do

@@ -1,5 +1,6 @@
 # Timing-only ablations of the cross-attention (D = 128) loop (results wrong by construction; never shipped).
 # usage on the GPU box: bash tools/exp_cross.sh
+. "$(dirname "${BASH_SOURCE[0]}")/exp/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 cd $GRAFT_REPO_ROOT/trajectorycrafter_amd/csrc
 BASE="-DTCX_EXP_NOLOAD -DTCX_EXP_NOWRITE -DTCX_EXP_NOBARRIER"
 i=0

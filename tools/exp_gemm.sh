@@ -1,5 +1,6 @@
 # Timing experiments on the GEMM kernel (some variants are deliberately unsafe: timing only, never shipped).
 # Usage on the GPU box: bash tools/exp_gemm.sh
+. "$(dirname "${BASH_SOURCE[0]}")/exp/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 cd $GRAFT_REPO_ROOT/trajectorycrafter_amd/csrc
 i=0
 for extra in "" "-DTCX_GEMM_EXP_DIRECT_RES" "" "-DTCX_GEMM_EXP_DIRECT_RES"; do

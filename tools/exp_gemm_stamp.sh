@@ -1,5 +1,6 @@
 # In-kernel stamps (s_memtime) of the GEMM: counts per main-loop iteration (2 K-tiles = 128 MFMAs per wave), prologue
 # and epilogue, for waves 0 and 7 of two workgroups.  Patches a COPY of gemm.hip.  Usage on the GPU box: bash tools/exp_gemm_stamp.sh
+. "$(dirname "${BASH_SOURCE[0]}")/exp/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 cd $GRAFT_REPO_ROOT/trajectorycrafter_amd/csrc
 python3 - <<'PY'
 s = open("gemm.hip").read()

@@ -1,4 +1,5 @@
 # A/B of the row kernels (norm.hip) on one box.  usage: bash tools/exp_norm.sh "<src[:flags]>" ...   e.g. "norm.hip" "norm_prev_exp.hip"
+. "$(dirname "${BASH_SOURCE[0]}")/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 cd $GRAFT_REPO_ROOT/trajectorycrafter_amd/csrc
 i=0
 for spec in "$@"; do

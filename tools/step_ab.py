@@ -1,7 +1,8 @@
 """In-process A/B of a module-level switch on the FULL denoising step (the bench's step: 42-layer model at 49f 480x720, CFG batch 2):
 alternating blocks of steps with the switch off / on, so that both arms see the same box, clock history and data.
-usage: python tools/step_ab.py [steps_per_block] [blocks] [switch]      switch: body16 (ops.ATTN_BODY16_DEFAULT, default) | cross_kv
-(model.cache_cross_kv: reuse of the cross-attention K / V across steps)"""
+usage: python tools/step_ab.py [steps_per_block] [blocks] [switch]      switch: cross_kv (default; model.cache_cross_kv: reuse of the
+cross-attention K / V across steps) | unproven | exact (model.set_softmax_path: the attention's other softmax loops, as in bench.py's
+bracket) | body16 (ops.ATTN_BODY16_DEFAULT — only in the patched copy: bash -c '. tools/exp/with_experiments.sh && python3 tools/step_ab.py 5 6 body16')"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,7 +12,9 @@ from trajectorycrafter_amd import ops
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-switch = sys.argv[3] if len(sys.argv) > 3 else "body16"
+switch = sys.argv[3] if len(sys.argv) > 3 else "cross_kv"
+if switch == "body16" and not hasattr(ops, "ATTN_BODY16_DEFAULT"):
+    raise SystemExit("the 16x16x32 body lives in tools/exp/attn_gemm_experiments.patch: bash -c '. tools/exp/with_experiments.sh && python3 tools/step_ab.py 5 6 body16'")
 args = bench.parse([])
 dev = torch.device("cuda:0")
 pipe = bench.build_models(args, dev)
@@ -32,6 +35,8 @@ for b in range(blocks):
     for flag in (False, True):
         if switch == "body16":
             ops.ATTN_BODY16_DEFAULT = flag
+        elif switch in ("unproven", "exact"):
+            pipe.transformer.set_softmax_path(switch if flag else "auto")
         else:
             pipe.transformer.cache_cross_kv = flag
             if flag:

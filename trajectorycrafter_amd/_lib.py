@@ -15,8 +15,6 @@ LIB_PATH = os.environ.get("TCX_LIB", os.path.join(_HERE, "libtcx_hip.so"))   # T
 TCX_BF16, TCX_F32 = 0, 1
 TCX_ATTN_LOG2_SCORES = 1
 TCX_ATTN_BOUND_PROVEN = 2
-TCX_ATTN_BODY_16X16X32 = 4
-TCX_ATTN_BODY_4WAVE = 8
 TCX_STEP_EULER, TCX_STEP_DPMPP_2M = 0, 1
 TCX_PNDM_PRK_FIRST, TCX_PNDM_PRK_MID, TCX_PNDM_PRK_LAST, TCX_PNDM_PLMS4 = 0, 1, 2, 3
 

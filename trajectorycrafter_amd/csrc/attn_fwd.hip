@@ -25,9 +25,12 @@
 //     relative, fp32 accumulators have the head-room), which makes it rare even on random data;
 //   * FAST path (D = 64, scores already in log2 units because the q/k-LayerNorm+RoPE kernel stores q
 //     pre-multiplied by scale*log2(e)): the running max enters as the INITIAL ACCUMULATOR of the QK^T
-//     MFMA chain (a persistent register block holding -m), so P = exp2(S') needs no FMA, and the row
-//     sum is one extra MFMA per 16 keys with an all-ones A operand instead of 32 VALU adds.
-//     Per score element that leaves exp2 + 1/2 cvt_pk + 1/2 max3 on the VALU.
+//     MFMA chain (a persistent register block holding -m), so P = exp2(S') needs no FMA.
+//     Per score element that leaves exp2 + 1 add + 1/2 cvt_pk + 1/2 max3 on the VALU.
+//
+// ONE loop body ships.  The bodies and timing-only ablations that were measured against it (v_mfma_f32_16x16x32_bf16 tiles, 4 waves
+// x 64 rows with asm MFMAs, row sums on the matrix pipe, LDS-DMA staging, in-kernel clock stamps, -DTCX_EXP_NO* builds) are patches
+// under tools/exp/ (attn_gemm_experiments.patch restores every one of them; DESIGN §3.1 has their numbers).
 #include <stdlib.h>
 #include <type_traits>
 #include "tcx_common.h"
@@ -52,15 +55,10 @@ struct AttnParams {
     size_t ws_bytes;
     uint32_t n_full, split;
     uint32_t proven;        // TCX_ATTN_BOUND_PROVEN: the caller guarantees M < 60 for every row -> no predicate, no complement launch
-    uint32_t body16;        // TCX_ATTN_BODY_16X16X32 (with proven, D = 64, bf16 out): the v_mfma_f32_16x16x32_bf16 loop body
 };
 // workspace of the tail split: per item (tail workgroup x part): O [256][D] fp32, then l [256] fp32 per item, then one flag word
 __host__ __device__ inline size_t attn_ws_o_floats(uint32_t items, int D) { return (size_t)items * 256 * D; }
 
-#ifndef TCX_ATTN_SUM_MFMA
-#define TCX_ATTN_SUM_MFMA 0
-#endif
-constexpr bool kSumMfma = TCX_ATTN_SUM_MFMA != 0;   // FAST path: row sum on the matrix pipe (1) or as VALU adds (0)
 constexpr float kDeferLog2 = 6.0f;   // rescale only when a row max grew by more than this (log2 units)
 
 template <int D>
@@ -151,17 +149,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 
     auto load_k = [&](auto jc, int tile) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;   // rows >= Sk read as zero (range check); tiles beyond the end too
-#ifdef TCX_EXP_NOLOAD
-        if (tile > 2 * R) return;
-#endif
 #pragma unroll
         for (int i = 0; i < NLD; ++i) kreg[j][i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[i] + tile * ktile_bytes, 0, 0);
     };
     auto load_v = [&](auto jc, int tile) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;   // zero V rows beyond Sk: P = 0 never meets garbage
-#ifdef TCX_EXP_NOLOAD
-        if (tile > 2 * R) return;
-#endif
 #pragma unroll
         for (int i = 0; i < NLD; ++i) vreg[j][i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[i] + tile * vtile_bytes, 0, 0);
     };
@@ -203,12 +195,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     float m = FAST ? 0.f : -INFINITY, l = 0.f;
     const float c = p.scale_log2;
     // FAST: -m replicated over an accumulator block (C-in of every S tile) and the MFMA row-sum accumulator
-    f32x16 minit, lacc;
+    f32x16 minit;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) minit[i] = 0.f, lacc[i] = 0.f;
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    for (int i = 0; i < 16; ++i) minit[i] = 0.f;
     bool first = true;
     float ls[4] = {0.f, 0.f, 0.f, 0.f};   // per-lane partial row sums since the last rescale (VALU row-sum paths)
     // Bound-centred variant of the FAST path: with M = |q_row| * max_k |k| >= every score of the row
@@ -297,19 +286,14 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             // deferral threshold, and unconditionally on the first tile (m starts at 0).
             if (first || !__all(mx <= kDeferLog2)) {            // wave-uniform
                 const float delta = first ? mx : fmaxf(mx, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-delta);   // first tile: o = lacc = 0, alpha irrelevant but finite
+                const float alpha = __builtin_amdgcn_exp2f(-delta);   // first tile: o = l = 0, alpha irrelevant but finite
                 m += delta;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) s[t][i] -= delta;    // this tile's scores were taken against the old m
-                if constexpr (kSumMfma) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) lacc[i] *= alpha;
-                } else {
-                    l = (l + (ls[0] + ls[1]) + (ls[2] + ls[3])) * alpha;
-                    ls[0] = ls[1] = ls[2] = ls[3] = 0.f;
-                }
+                l = (l + (ls[0] + ls[1]) + (ls[2] + ls[3])) * alpha;
+                ls[0] = ls[1] = ls[2] = ls[3] = 0.f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) minit[i] = -m;
 #pragma unroll
@@ -357,20 +341,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             for (int j = 0; j < KPS; ++j)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-#ifdef TCX_EXP_NOLDS
-                    kf[j][t] = qf[(st + j + t) % KS];
-#else
                     kf[j][t] = *reinterpret_cast<const bf16x8*>(kb + koff[st * KPS + j] + t * K_T_STRIDE);
-#endif
                 }
         }
         const int rowb = (32 * (st >> 1) + 16 * (st & 1)) * (D * 2);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-#ifdef TCX_EXP_NOLDS
-            vf[dt] = qf[(st + dt + 1) % KS];
-            (void)rowb;
-#else
             auto p0 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + rowb);
             auto p1 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + rowb + 8 * (D * 2));
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0);
@@ -378,7 +354,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             typedef __attribute__((ext_vector_type(8))) short s16x8;
             const s16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             vf[dt] = __builtin_bit_cast(bf16x8, av);
-#endif
         }
     };
     auto tile_body = [&](auto has_next, const char* kb, const char* vb, f32x16 (&cur)[2], f32x16 (&nxt)[2]) __attribute__((always_inline)) {
@@ -404,27 +379,18 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float e;
-#ifdef TCX_EXP_NOEXP
-                e = cur[t][8 * s2 + j];
-#else
                 if constexpr (FAST) {
                     e = __builtin_amdgcn_exp2f(cur[t][8 * s2 + j]);
-                    if constexpr (!kSumMfma) ls[j & 3] += e;
+                    ls[j & 3] += e;
                 } else {
                     e = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[t][8 * s2 + j], c, -m));
                     ls[j & 3] += e;
                 }
-#endif
                 pf[j] = (__bf16)e;
             }
 #pragma unroll
-#ifdef TCX_EXP_NOPV
-            asm volatile("" ::"v"(pf), "v"(vf[0]), "v"(vf[DT - 1]));
-#else
             for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pf, o[dt], 0, 0, 0);
-#endif
-            if constexpr (FAST && kSumMfma) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);   // row sum on the matrix pipe
-            else asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]));   // pin the partial sums here: without a use
+            asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]));   // pin the partial sums here: without a use
             // inside the loop (bound-centred variant) the add chains get sunk to the loop end and 64 exponentials stay live
             __builtin_amdgcn_sched_barrier(0);       // keep the four steps in this order (no re-bunching)
         };
@@ -448,30 +414,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     // order they slip one MFMA apart and mesh.  The PV product of a 16-key step is delayed by one step (pprev / vprev:
     // its P fragment and V fragments stay in registers) so that it can alternate with the next step's exponentials;
     // the last one is flushed after the loop.
-#ifdef TCX_EXP_NOFINE
-    constexpr bool FINE = false;
-#else
-    constexpr bool FINE = BOUND && FAST && D == 64 && !kSumMfma;
-#endif
-    // Row sums of the fine loop: 32 v_add per tile (default) or one ones . P^T MFMA per 16-key step (-DTCX_ATTN_FINE_SUM_MFMA).  On
-    // THIS body the MFMA form loses 6 % (7.24 vs 6.83 ms, tools/exp/attn_variants.sh, round 3; round 2 measured the same on the coarse
-    // loop): 20 instead of 16 32x32x16 MFMAs per tile put the matrix pipe at 76 % of the tile time and the kernel at 256 VGPRs with
-    // spills — whereas the 16x16x32 body below gains 3.3 % from it (its extra MFMA is 16 cycles, its issue budget the tighter one).
-#ifdef TCX_ATTN_FINE_SUM_MFMA
-    constexpr bool FSUM = FINE;
-#else
-    constexpr bool FSUM = false;
-#endif
-    // Third form (-DTCX_ATTN_FINE_SUM_4X4): v_mfma_f32_4x4x4_16b_bf16 with an all-ones A operand adds the FOUR bf16 values a lane
-    // holds in two packed P registers into that lane's accumulator (every block row of ones . B is the column sum, and a lane's
-    // column is its own k-values): 2 short MFMAs per 16-key step (8 per tile) instead of 32 v_add.
-#ifdef TCX_ATTN_FINE_SUM_4X4
-    constexpr bool F4 = FINE && !FSUM;
-#else
-    constexpr bool F4 = false;
-#endif
-    f32x4 lacc4 = {0.f, 0.f, 0.f, 0.f}, lacc4b = {0.f, 0.f, 0.f, 0.f};
-    const s16x4 ones4 = {0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    // Row sums: 32 v_add per tile.  The two matrix-pipe forms that were measured (one ones . P^T 32x32x16 MFMA per 16-key step: -6 %;
+    // eight v_mfma_f32_4x4x4_16b_bf16 per tile: -0.5 %) live in tools/exp/attn_gemm_experiments.patch, DESIGN §3.1.
+    constexpr bool FINE = BOUND && FAST && D == 64;
     bf16x8 pprev, vprev[DT];
 #pragma unroll
     for (int j = 0; j < 8; ++j) pprev[j] = (__bf16)0.0f;
@@ -482,12 +427,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     bf16x8 kfa[2], kfb[2];
     auto tile_body_fine = [&](auto has_next, auto prefetched, const char* kb, const char* kb_after, const char* vb, f32x16 (&cur)[2],
                               f32x16 (&nxt)[2]) __attribute__((always_inline)) {
-#ifdef TCX_EXP_NOKPRE
-        constexpr bool NEXT = decltype(has_next)::value, PRE = false;
-        kb_after = nullptr;
-#else
         constexpr bool NEXT = decltype(has_next)::value, PRE = decltype(prefetched)::value;
-#endif
         auto read_k_from = [&](const char* base, int st, bf16x8 (&kf)[2]) __attribute__((always_inline)) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(base + koff[st] + t * K_T_STRIDE);
@@ -511,10 +451,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             auto soft2 = [&](int j0) __attribute__((always_inline)) {
                 const float e0 = __builtin_amdgcn_exp2f(cur[t][8 * s2 + j0]);
                 const float e1 = __builtin_amdgcn_exp2f(cur[t][8 * s2 + j0 + 1]);
-                if constexpr (!FSUM && !F4) {
-                    ls[j0 & 3] += e0;
-                    ls[(j0 + 1) & 3] += e1;
-                }
+                ls[j0 & 3] += e0;
+                ls[(j0 + 1) & 3] += e1;
                 uint32_t w = pack_bf16(e0, e1);
                 asm volatile("" : "+v"(w));              // convert here, inside this MFMA gap (the compiler sinks all four to the step's end)
                 pw[j0 >> 1] = w;
@@ -524,21 +462,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
                 else if (kb_after) read_k_from(kb_after, 0, kfn);      // step 3: kfn is kfa, what the next tile's step 0 uses
             }
             o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vprev[0], pprev, o[0], 0, 0, 0);
-            if constexpr (F4) {                          // the previous step's P (converted a step ago: no VALU -> MFMA wait states)
-                const u32x4 pv = __builtin_bit_cast(u32x4, pprev);
-                const u32x2 lo = {pv[0], pv[1]};
-                lacc4 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, lo), lacc4, 0, 0, 0);
-            }
             soft2(0);
             __builtin_amdgcn_sched_barrier(0);
             read_v(st, 0, vcur[0]);
             o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vprev[1], pprev, o[1], 0, 0, 0);
-            if constexpr (FSUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pprev, lacc, 0, 0, 0);
-            if constexpr (F4) {
-                const u32x4 pv = __builtin_bit_cast(u32x4, pprev);
-                const u32x2 hi = {pv[2], pv[3]};
-                lacc4b = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, hi), lacc4b, 0, 0, 0);
-            }
             soft2(2);
             __builtin_amdgcn_sched_barrier(0);
             read_v(st, 1, vcur[1]);
@@ -547,7 +474,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (NEXT) nxt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[st], chain_c(st == 0, nxt[1]), 0, 0, 0);
             soft2(6);
-            if constexpr (!FSUM && !F4) asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]));
+            asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]));
             __builtin_amdgcn_sched_barrier(0);
             pf = __builtin_bit_cast(bf16x8, pw);
 
@@ -603,17 +530,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             if constexpr (PH == 0) one_tile(bnd, masked, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t0, sa, sb, std::false_type{}, nullptr);
             else one_tile(bnd, masked, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t0, sb, sa, std::false_type{}, nullptr);
         }
-#ifndef TCX_EXP_NOWRITE
         write_k(J0, (PH + TPB + 1) % R);
         write_v(J0, (PH + TPB) % R);
         if constexpr (TPB == 2) {
             write_k(J1, (PH + TPB + 2) % R);
             write_v(J1, (PH + TPB + 1) % R);
         }
-#endif
-#ifndef TCX_EXP_NOBARRIER
         __syncthreads();
-#endif
     };
     // tiles left after the last full super-step: fewer than TPB steps with a successor (everything they read is
     // already resident: no staging, no barrier), then the peeled last tile (no successor)
@@ -657,10 +580,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     if constexpr (!bounded) row_max_and_rescale(sa);
     __syncthreads();                      // slot 0 of K is overwritten at the end of the first super-step
 
-#ifdef TCX_ATTN_STAMP                  // diagnostic build only (tools/clock_stamps.sh)
-    const unsigned long long tC0 = __builtin_amdgcn_s_memtime(), tR0 = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
     auto run = [&](auto bnd) __attribute__((always_inline)) {
         int t0 = 0;
         // steady state: a pair of super-steps computes the scores up to tile t0 + 2 TPB; while that is not the last tile: no mask
@@ -681,32 +600,14 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         }
     };
     run(std::integral_constant<bool, BOUND>{});
-#ifdef TCX_ATTN_STAMP
-    {
-        const unsigned long long tC1 = __builtin_amdgcn_s_memtime(), tR1 = __builtin_amdgcn_s_memrealtime();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        if (BOUND && (blockIdx.x % 997 == 5) && lane == 0 && (wave == 0 || wave == 7))
-            printf("ASTAMP body 32 D %d wg %d wave %d tiles %d cycles %llu real %llu\n", D, (int)blockIdx.x, wave, ntiles, tC1 - tC0, tR1 - tR0);
-    }
-#endif
     if constexpr (FINE) {                 // the delayed PV product of the very last 16-key step
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vprev[dt], pprev, o[dt], 0, 0, 0);
-        if constexpr (FSUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pprev, lacc, 0, 0, 0);
-        if constexpr (F4) {
-            const u32x4 pv = __builtin_bit_cast(u32x4, pprev);
-            const u32x2 lo = {pv[0], pv[1]}, hi = {pv[2], pv[3]};
-            lacc4 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, lo), lacc4, 0, 0, 0);
-            lacc4b = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, hi), lacc4b, 0, 0, 0);
-        }
     }
-    if constexpr (F4) l += lacc4[0] + lacc4b[0];
-    else if constexpr (!(FAST && kSumMfma) && !FSUM) l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+    l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
 
     // ---- epilogue: combine the two half-wave partial sums, normalise, store O[q][d] ----
-    if constexpr ((FAST && kSumMfma) || FSUM) {
-        l = lacc[0];                      // every row of the ones-product holds the full row sum (both half-waves)
-    } else {
+    {
         const uint32_t u = __float_as_uint(l);
         auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
         l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
@@ -726,7 +627,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     }
     const float inv = 1.0f / l;
     const int qrow = q0 + r;
-#ifndef TCX_EXP_DIRECT_OSTORE
     if constexpr (!OUT_F32) {
         // bf16 output through the wave's own 32 x (2 D)-byte LDS tile (16-byte chunk c of row q at c ^ (q & 7)) so that it
         // leaves as row-wise 16-byte stores (full lines) instead of 4 DT scattered 8-byte stores per lane (store-issue bound)
@@ -755,7 +655,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         }
         return;
     }
-#endif
     if (qrow < p.Sq) {
         const int64_t ooff = (int64_t)b * p.osb + (int64_t)qrow * p.oss + (int64_t)hd * p.osh;
 #pragma unroll
@@ -774,745 +673,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
                     *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.o) + ooff + d0) = w;
                 }
             }
-    }
-}
-
-// ---- the bound-centred D = 64 loop on v_mfma_f32_16x16x32_bf16 (round 3 experiment: MI355X_MICROARCH.md DVFS item 7 reports that a
-// 16x16x32 loop holds a higher clock than the 32x32x16 loop at equal cycles per FLOP) ---------------------------------------------
-// Same work decomposition, staging, LDS ring and barrier structure as attn_fwd_kernel<64, false, true, 8, true>; what changes is the
-// MFMA tiling of a wave's 32 query rows x 64 keys:
-//   S^T[key, q] = K . Q^T as 4 (key tiles of 16) x 2 (query tiles of 16) accumulators f32x4, 2 k-steps of 32 each: lane (c16 = lane & 15,
-//     g = lane >> 4) holds S^T[16 kt + 4 g + i][16 qt + c16], i = 0..3 — a query row is spread over the 4 lanes c16 + 16 g, its row
-//     sum stays a per-lane partial until the epilogue (the bound-centred softmax needs no row max).
-//   O^T[d, q] += V^T . P^T with K = 32 keys per MFMA: the B operand of (key pair kk, query tile qt) is pack(P[2 kk][qt], P[2 kk + 1][qt])
-//     straight from the accumulators, i.e. operand index 8 g + c <-> key 32 kk + 16 (c >> 2) + 4 g + (c & 3); the A operand follows the
-//     same map: two ds_read_b64_tr_b16 per (kk, d tile), rows 32 kk + 4 g + q4 and + 16, from a V image whose 32-byte units are XORed
-//     with (row >> 1) & 3 (conflict-free for this access: tools/exp/lds_conflicts.py).
-//   A tile = 4 steps (kk, qt); step: 4 PV MFMAs of the PREVIOUS step's P (delayed by one step so they alternate with this step's
-//     exponentials), 4 QK^T MFMAs of the next tile, and after every MFMA exactly {1 exp, 1 add} (+ 1 cvt_pk every other).
-// Only launched with TCX_ATTN_BOUND_PROVEN (no per-workgroup predicate: the exact kernel computes |q|^2 in the 32x32 lane order and
-// must agree bit for bit with whoever evaluates the predicate).
-__device__ __forceinline__ int v16_off(int row, int ch) { return row * 128 + ((((ch >> 1) ^ ((row >> 1) & 3))) << 5) + ((ch & 1) << 4); }
-
-__global__ __launch_bounds__(512) void attn_fwd16_kernel(const AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int D = 64, TILEB = 64 * D * 2, TPB = 2, R = 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c16 = lane & 15, g = lane >> 4;
-
-    uint32_t pb = blockIdx.x;
-    int part = -1;
-    uint32_t item = 0;
-    if (p.split > 1 && pb >= p.n_full) {
-        item = pb - p.n_full;
-        part = (int)(item % p.split);
-        pb = p.n_full + item / p.split;
-    }
-    const uint32_t id = xcd_remap(pb, p.nwg);
-    const uint32_t bh = id / p.nqb, qb = id - bh * p.nqb;
-    const int b = bh / p.H, hd = bh - b * p.H;
-    const int q0 = qb * 256 + wave * 32;
-
-    const uint16_t* kbase = p.k + (int64_t)b * p.ksb + (int64_t)hd * p.ksh;
-    const uint16_t* vbase = p.v + (int64_t)b * p.vsb + (int64_t)hd * p.vsh;
-    int Sk = p.Sk;
-    if (part >= 0) {
-        const int T = (p.Sk + 63) >> 6;
-        const int t_lo = (int)((int64_t)part * T / p.split), t_hi = (int)((int64_t)(part + 1) * T / p.split);
-        kbase += (int64_t)t_lo * 64 * p.kss;
-        vbase += (int64_t)t_lo * 64 * p.vss;
-        Sk = min(p.Sk, t_hi * 64) - t_lo * 64;
-    }
-    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)((((int64_t)Sk - 1) * p.kss + D) * 2), 0x00020000);
-    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)((((int64_t)Sk - 1) * p.vss + D) * 2), 0x00020000);
-    const int ktile_bytes = (int)(64 * p.kss * 2), vtile_bytes = (int)(64 * p.vss * 2);
-    const int ntiles = (Sk + 63) >> 6;
-
-    // ---- Q fragments (B operand of QK^T): lane holds Q[q0 + 16 qt + c16][32 ks + 8 g .. + 8] ----
-    bf16x8 qf[2][2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        int qrow = q0 + 16 * qt + c16;
-        if (qrow >= p.Sq) qrow = p.Sq - 1;
-        const uint16_t* qp = p.q + (int64_t)b * p.qsb + (int64_t)qrow * p.qss + (int64_t)hd * p.qsh + 8 * g;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
-    }
-    // exponent origin M = |q_row| max|k| >= every score of the row (same value in every lane of the row and in every split part)
-    float negM[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        float qsq = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float qv = (float)qf[qt][ks][j];
-                qsq = __builtin_fmaf(qv, qv, qsq);
-            }
-        qsq += __shfl_xor(qsq, 16);
-        qsq += __shfl_xor(qsq, 32);
-        negM[qt] = -(sqrtf(qsq * p.k_sqmax[bh]) * 1.002f + 1e-3f);
-    }
-    if (part >= 0 && tid == 0)
-        reinterpret_cast<uint32_t*>(p.ws + attn_ws_o_floats(p.split * (p.nwg - p.n_full), D) + (size_t)p.split * (p.nwg - p.n_full) * 256)[item] = 1u;
-
-    // ---- staging: thread -> (row, 16-byte chunk) of a 64-row tile ----
-    const int srow = tid >> 3, sch = tid & 7;
-    const int kvoff = (int)(srow * p.kss * 2) + sch * 16, vvoff = (int)(srow * p.vss * 2) + sch * 16;
-    const int klds = k_off<64>(srow, sch), vlds = v16_off(srow, sch);
-    u32x4 kreg[TPB], vreg[TPB];
-    auto load_k = [&](auto jc, int tile) __attribute__((always_inline)) { kreg[decltype(jc)::value] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff + tile * ktile_bytes, 0, 0); };
-    auto load_v = [&](auto jc, int tile) __attribute__((always_inline)) { vreg[decltype(jc)::value] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff + tile * vtile_bytes, 0, 0); };
-    char* const kbuf0 = smem;
-    char* const vbuf0 = smem + R * TILEB;
-    auto write_k = [&](auto jc, int slot) __attribute__((always_inline)) { *reinterpret_cast<u32x4*>(kbuf0 + slot * TILEB + klds) = kreg[decltype(jc)::value]; };
-    auto write_v = [&](auto jc, int slot) __attribute__((always_inline)) { *reinterpret_cast<u32x4*>(vbuf0 + slot * TILEB + vlds) = vreg[decltype(jc)::value]; };
-
-    // ---- LDS read bases ----
-    // K fragment (kt, ks): row 16 kt + c16, chunk 4 ks + g.  k_off's XOR term sees (row >> 1) & 15 = (c16 >> 1) | ((kt & 1) << 3): one base
-    // per (kt parity, ks), kt adds 2048 bytes.
-    int koff[2][2];
-#pragma unroll
-    for (int par = 0; par < 2; ++par)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) koff[par][ks] = k_off<64>(16 * par + c16, 4 * ks + g) - par * 2048;
-    // V^T fragment (kk, hi, dt): the lane supplies row 32 kk + 16 hi + 4 g + q4, columns 16 dt + 4 pp .. + 3
-    const int q4 = c16 >> 2, pp = c16 & 3;
-    int voff[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) voff[dt] = v16_off(4 * g + q4, 2 * dt + (pp >> 1)) + ((pp & 1) << 3);
-
-    f32x4 o[4][2];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // row sums on the matrix pipe: ones(16 x 32) . P^T, one more MFMA per P operand (4 per tile, +12 % matrix work) instead of 32 v_add
-    // per tile in a loop whose limiter is the SIMD's instruction issue: +3.3 % measured (tools/attn_body_bench.py), and numerator and
-    // denominator now use the SAME bf16-rounded P (the oracle's contract, dr.sdpa_log2).  Every row of the product holds the sums.
-    f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-    f32x4 sa[4][2], sb[4][2];                              // S^T of the current / next tile: [kt][qt]
-    bf16x8 pprev, vfa[4], vfb[4], kfa[2], kfb[2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) pprev[j] = (__bf16)0.0f;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) vfa[dt] = vfb[dt] = pprev;
-
-    // -M as the C operand of the first MFMA of every QK^T chain (destination = the S tile): S' = K Q^T - M with no per-tile copies
-    f32x4 cinit[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) cinit[qt] = f32x4{negM[qt], negM[qt], negM[qt], negM[qt]};
-    auto read_k = [&](const char* kb, int kt, bf16x8 (&kf)[2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(kb + koff[kt & 1][ks] + kt * 2048);
-    };
-    auto read_vset = [&](const char* vb, int kk, bf16x8 (&vf)[4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            auto p0 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + (32 * kk) * 128);
-            auto p1 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + (32 * kk + 16) * 128);
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0);
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p1);
-            vf[dt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        }
-    };
-    auto mask_tail = [&](f32x4 (&s)[4][2]) {              // keys >= Sk of the last tile
-        const int kv0 = (ntiles - 1) * 64 + 4 * g;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (kv0 + 16 * kt + i >= Sk) s[kt][qt][i] = -INFINITY;
-    };
-
-    // one step (KK, QT) of a tile: PV of the previous step's P | exponentials of cur[2 KK .. 2 KK + 1][QT] | QK^T of nxt[J = 2 KK + QT]
-    auto step = [&](auto has_next, auto jc, const char* kb, const char* vb, f32x4 (&cur)[4][2], f32x4 (&nxt)[4][2], bf16x8 (&kf)[2],
-                    bf16x8 (&kfn)[2]) __attribute__((always_inline)) {
-        constexpr bool NEXT = decltype(has_next)::value;
-        constexpr int J = decltype(jc)::value, KK = J >> 1, QT = J & 1;
-        constexpr int QP = 1 - QT;                         // query tile of the previous step's P
-        // operands needed one step from now: the next step's K fragments; at QT == 0 the V fragments of THIS key pair (used by the PV
-        // MFMAs of step (KK, 1) and of the step after it)
-        if constexpr (NEXT && J < 3) read_k(kb, J + 1, kfn);
-        if constexpr (QT == 0) {
-            if constexpr (KK == 0) read_vset(vb, 0, vfa);
-            else read_vset(vb, 1, vfb);
-        }
-        // the PV MFMAs of this step use the V set of the previous step's key pair: (KK, 0) -> pair KK - 1 (other buffer), (KK, 1) -> pair KK
-        bf16x8 (&vf)[4] = ((KK == 0) == (QT == 1)) ? vfa : vfb;
-        u32x4 pw;
-        float e[8];
-        auto soft = [&](int i) __attribute__((always_inline)) {
-            e[i] = __builtin_amdgcn_exp2f(cur[2 * KK + (i >> 2)][QT][i & 3]);
-            if (i & 1) {
-                uint32_t w = pack_bf16(e[i - 1], e[i]);
-                asm volatile("" : "+v"(w));               // convert here, in this gap
-                pw[i >> 1] = w;
-            }
-        };
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            o[dt][QP] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pprev, o[dt][QP], 0, 0, 0);
-            if (dt == 3) lacc[QP] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pprev, lacc[QP], 0, 0, 0);
-            soft(dt);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            if constexpr (NEXT) nxt[J][n & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[n >> 1], qf[n & 1][n >> 1], n < 2 ? cinit[n & 1] : nxt[J][n & 1], 0, 0, 0);
-            soft(4 + n);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        pprev = __builtin_bit_cast(bf16x8, pw);
-    };
-    auto tile = [&](auto has_next, const char* kb, const char* vb, f32x4 (&cur)[4][2], f32x4 (&nxt)[4][2]) __attribute__((always_inline)) {
-        constexpr bool NEXT = decltype(has_next)::value;
-        if constexpr (NEXT) read_k(kb, 0, kfa);
-        step(has_next, std::integral_constant<int, 0>{}, kb, vb, cur, nxt, kfa, kfb);
-        step(has_next, std::integral_constant<int, 1>{}, kb, vb, cur, nxt, kfb, kfa);
-        step(has_next, std::integral_constant<int, 2>{}, kb, vb, cur, nxt, kfa, kfb);
-        step(has_next, std::integral_constant<int, 3>{}, kb, vb, cur, nxt, kfb, kfa);
-    };
-
-    constexpr std::integral_constant<int, 0> J0{};
-    constexpr std::integral_constant<int, 1> J1{};
-    auto one_tile = [&](auto masked, auto slot_k, auto slot_v, int t, f32x4 (&cur)[4][2], f32x4 (&nxt)[4][2]) __attribute__((always_inline)) {
-        tile(std::true_type{}, kbuf0 + decltype(slot_k)::value * TILEB, vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
-        if constexpr (decltype(masked)::value) {          // only the super-steps that can reach the last key tile (see attn_fwd_kernel)
-            if (t + 1 == ntiles - 1 && (Sk & 63)) mask_tail(nxt);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // ring / barrier structure of attn_fwd_kernel (see there): tile t in slot t % R; a super-step = 2 tiles, one barrier
-    auto super_step = [&](auto masked, auto ph, int t0) __attribute__((always_inline)) {
-        constexpr int PH = decltype(ph)::value;
-        load_k(J0, t0 + TPB + 1);
-        load_v(J0, t0 + TPB);
-        load_k(J1, t0 + TPB + 2);
-        load_v(J1, t0 + TPB + 1);
-        one_tile(masked, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
-        one_tile(masked, std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa);
-        write_k(J0, (PH + TPB + 1) % R);
-        write_v(J0, (PH + TPB) % R);
-        write_k(J1, (PH + TPB + 2) % R);
-        write_v(J1, (PH + TPB + 1) % R);
-        __syncthreads();
-    };
-    auto tail = [&](auto ph, int t0) __attribute__((always_inline)) {
-        constexpr int PH = decltype(ph)::value;
-        const int rem = (ntiles - 1) - t0;                 // 0 or 1 tiles with a successor, then the last tile
-        if (rem == 1) {
-            one_tile(std::true_type{}, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
-            tile(std::false_type{}, kbuf0, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
-        } else {
-            tile(std::false_type{}, kbuf0, vbuf0 + (PH % R) * TILEB, sa, sb);
-        }
-    };
-
-    // prologue: K[0 .. 2], V[0 .. 1] into their slots, S(0)
-    load_k(J0, 0);
-    load_v(J0, 0);
-    load_k(J1, 1);
-    load_v(J1, 1);
-    write_k(J0, 0);
-    write_v(J0, 0);
-    write_k(J1, 1);
-    write_v(J1, 1);
-    load_k(J0, TPB);
-    write_k(J0, TPB % R);
-    __syncthreads();
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        read_k(kbuf0, kt, kfa);
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-            sa[kt][n & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfa[n >> 1], qf[n & 1][n >> 1], n < 2 ? cinit[n & 1] : sa[kt][n & 1], 0, 0, 0);
-    }
-    if (ntiles == 1 && (Sk & 63)) mask_tail(sa);
-    __syncthreads();
-
-#ifdef TCX_ATTN_STAMP                  // diagnostic build only (tools/clock_stamps.sh): cycles and 100 MHz ticks around the main loop
-    const unsigned long long tC0 = __builtin_amdgcn_s_memtime(), tR0 = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
-    {
-        int t0 = 0;
-        for (; t0 + 2 * TPB < ntiles - 1; t0 += 2 * TPB) {   // steady state: never reaches the last key tile -> no mask code
-            super_step(std::false_type{}, std::integral_constant<int, 0>{}, t0);
-            super_step(std::false_type{}, std::integral_constant<int, TPB>{}, t0 + TPB);
-        }
-        if (t0 + 2 * TPB <= ntiles - 1) {
-            super_step(std::true_type{}, std::integral_constant<int, 0>{}, t0);
-            super_step(std::true_type{}, std::integral_constant<int, TPB>{}, t0 + TPB);
-            t0 += 2 * TPB;
-        }
-        if (t0 + TPB <= ntiles - 1) {
-            super_step(std::true_type{}, std::integral_constant<int, 0>{}, t0);
-            tail(std::integral_constant<int, TPB>{}, t0 + TPB);
-        } else {
-            tail(std::integral_constant<int, 0>{}, t0);
-        }
-    }
-#ifdef TCX_ATTN_STAMP
-    {
-        const unsigned long long tC1 = __builtin_amdgcn_s_memtime(), tR1 = __builtin_amdgcn_s_memrealtime();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        if ((blockIdx.x % 997 == 5) && lane == 0 && (wave == 0 || wave == 7))
-            printf("ASTAMP body 16 D 64 wg %d wave %d tiles %d cycles %llu real %llu\n", (int)blockIdx.x, wave, ntiles, tC1 - tC0, tR1 - tR0);
-    }
-#endif
-    // the delayed PV product of the very last step (key pair 1 -> V set B, query tile 1)
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfb[dt], pprev, o[dt][1], 0, 0, 0);
-    lacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pprev, lacc[1], 0, 0, 0);
-
-    // ---- epilogue: normalise, store ----
-    const float l[2] = {lacc[0][0], lacc[1][0]};           // every row of ones . P^T holds the row sums over all keys (all four g)
-    if (part >= 0) {                                        // split part: un-normalised O (fp32) and the row sum go to the workspace
-        const uint32_t items = p.split * (p.nwg - p.n_full);
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            float* wo = p.ws + ((size_t)item * 256 + wave * 32 + 16 * qt + c16) * D;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(wo + 16 * dt + 4 * g) = o[dt][qt];
-            if (g == 0) p.ws[attn_ws_o_floats(items, D) + (size_t)item * 256 + wave * 32 + 16 * qt + c16] = l[qt];
-        }
-        return;
-    }
-    constexpr int RB = D * 2;
-    __syncthreads();                                       // every wave is past its last K / V fragment read
-    char* ot = smem + wave * (32 * RB);                    // 32 rows x 128 B; 16-byte chunk c of row r at c ^ (r & 7)
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const float inv = 1.0f / l[qt];
-        const int r = 16 * qt + c16;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int d0 = 16 * dt + 4 * g;
-            u32x2 w;
-            w[0] = pack_bf16(o[dt][qt][0] * inv, o[dt][qt][1] * inv);
-            w[1] = pack_bf16(o[dt][qt][2] * inv, o[dt][qt][3] * inv);
-            *reinterpret_cast<u32x2*>(ot + r * RB + (((d0 >> 3) ^ (r & 7)) << 4) + ((d0 & 4) << 1)) = w;
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int rl = lane >> 3, ch = lane & 7;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = i * 8 + rl;
-        const u32x4 val = *reinterpret_cast<const u32x4*>(ot + row * RB + ((ch ^ (row & 7)) << 4));
-        const int qr = q0 + row;
-        if (qr < p.Sq)
-            *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.osb + (int64_t)qr * p.oss + (int64_t)hd * p.osh + 8 * ch) = val;
-    }
-}
-
-// ---- 4 waves x 64 query rows: one wave per SIMD, the whole 512-entry register file (round 3) ---------------------------------------
-// Why: the 8-wave loop is bound by the SIMD's instruction issue (2 waves x ~840 issue cycles per tile); its fragment reads, waits and
-// staging are paid once per 32 query rows.  Here a wave owns TWO 32-row query blocks (A, B) that share every K / V fragment read and
-// every staging instruction, the row sums go to the matrix pipe (ones . P^T), and nothing is centred (|S| <= M < 60 is guaranteed by
-// TCX_ATTN_BOUND_PROVEN, so P = exp2(S) cannot overflow and the scale cancels in O / l): per 64-key tile a wave issues 40 MFMA
-// (1280 matrix-pipe cycles) beside 64 v_exp_f32 + 32 v_cvt_pk + 24 LDS reads (~1200 issue cycles) instead of 2 x 840.
-// Register plan (hipcc picks ONE register form per MFMA builtin per function, so the MFMAs are inline asm with explicit classes):
-// S tiles of both blocks (exp inputs) in arch VGPRs, O / row-sum accumulators and the Q fragments in AGPRs, never copied in the loop.
-// The kernel must stay SPILL-FREE (checked: 225 + 228 registers, scratch 0): a compiler spill store or copy of an S tile placed right
-// behind an asm MFMA would read registers the MFMA has not written yet — hipcc pads no hazards around asm statements.
-// Hazards the asm statements hide from hipcc (cdna_hip_programming.md 5.7) are kept away by construction: P is converted one slot
-// (5 MFMAs) before the MFMA that reads it, K / V fragments arrive by counted LDS reads, S tiles are exponentiated >= 5 MFMAs after
-// the last MFMA that wrote them, the epilogue waits out the last MFMA explicitly.
-namespace mf {
-__device__ __forceinline__ void s_first(f32x16& d, const bf16x8& k, const bf16x8& q) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
-}
-__device__ __forceinline__ void s_acc(f32x16& d, const bf16x8& k, const bf16x8& q) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
-}
-__device__ __forceinline__ void o_acc(f32x16& acc, const bf16x8& a, const bf16x8& pfrag) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(pfrag));
-}
-__device__ __forceinline__ void o_acc_nop(f32x16& acc, const bf16x8& a, const bf16x8& pfrag) {       // pfrag may have been written by the
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(pfrag));   // VALU instruction just before
-}
-__device__ __forceinline__ void l_acc(f32x16& acc, const bf16x8& ones_a, const bf16x8& pfrag) {     // A operand (all ones) in AGPRs
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(ones_a), "v"(pfrag));
-}
-}  // namespace mf
-
-__global__ __launch_bounds__(256) void attn_fwd4_kernel(const AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int D = 64, TILEB = 64 * D * 2, TPB = 2, R = 4, NLD = 2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-
-    uint32_t pb = blockIdx.x;
-    int part = -1;
-    uint32_t item = 0;
-    if (p.split > 1 && pb >= p.n_full) {
-        item = pb - p.n_full;
-        part = (int)(item % p.split);
-        pb = p.n_full + item / p.split;
-    }
-    const uint32_t id = xcd_remap(pb, p.nwg);
-    const uint32_t bh = id / p.nqb, qb_ = id - bh * p.nqb;
-    const int b = bh / p.H, hd = bh - b * p.H;
-    const int q0 = qb_ * 256 + wave * 64;                  // this wave: rows q0 .. q0 + 63 = blocks A (q0 ..) and B (q0 + 32 ..)
-
-    const uint16_t* kbase = p.k + (int64_t)b * p.ksb + (int64_t)hd * p.ksh;
-    const uint16_t* vbase = p.v + (int64_t)b * p.vsb + (int64_t)hd * p.vsh;
-    int Sk = p.Sk;
-    if (part >= 0) {
-        const int T = (p.Sk + 63) >> 6;
-        const int t_lo = (int)((int64_t)part * T / p.split), t_hi = (int)((int64_t)(part + 1) * T / p.split);
-        kbase += (int64_t)t_lo * 64 * p.kss;
-        vbase += (int64_t)t_lo * 64 * p.vss;
-        Sk = min(p.Sk, t_hi * 64) - t_lo * 64;
-    }
-    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)((((int64_t)Sk - 1) * p.kss + D) * 2), 0x00020000);
-    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)((((int64_t)Sk - 1) * p.vss + D) * 2), 0x00020000);
-    const int ktile_bytes = (int)(64 * p.kss * 2), vtile_bytes = (int)(64 * p.vss * 2);
-    const int ntiles = (Sk + 63) >> 6;
-    if (part >= 0 && tid == 0)
-        reinterpret_cast<uint32_t*>(p.ws + attn_ws_o_floats(p.split * (p.nwg - p.n_full), D) + (size_t)p.split * (p.nwg - p.n_full) * 256)[item] = 1u;
-
-    // ---- Q fragments (B operand of QK^T, AGPRs): lane holds Q[q0 + 32 blk + r][16 ks + 8 h .. + 8] ----
-    bf16x8 qf[2][4];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        int qrow = q0 + 32 * blk + r;
-        if (qrow >= p.Sq) qrow = p.Sq - 1;
-        const uint16_t* qp = p.q + (int64_t)b * p.qsb + (int64_t)qrow * p.qss + (int64_t)hd * p.qsh + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[blk][ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
-    }
-
-    // ---- staging: global -> registers -> LDS (issue early / write late), 2 x 16 bytes per thread per operand and tile ----
-    int kvoff[NLD], vvoff[NLD], klds[NLD], vlds[NLD];
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int idx = tid + i * 256;
-        const int row = idx >> 3, ch = idx & 7;
-        kvoff[i] = (int)(row * p.kss * 2) + ch * 16;
-        vvoff[i] = (int)(row * p.vss * 2) + ch * 16;
-        klds[i] = k_off<64>(row, ch);
-        vlds[i] = v_chunk_off<64>(row, ch);
-    }
-    u32x4 kreg[TPB][NLD], vreg[TPB][NLD];
-    auto load_k = [&](auto jc, int tile) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) kreg[decltype(jc)::value][i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[i] + tile * ktile_bytes, 0, 0);
-    };
-    auto load_v = [&](auto jc, int tile) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) vreg[decltype(jc)::value][i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[i] + tile * vtile_bytes, 0, 0);
-    };
-    char* const kbuf0 = smem;
-    char* const vbuf0 = smem + R * TILEB;
-    auto write_k = [&](auto jc, int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(kbuf0 + slot * TILEB + klds[i]) = kreg[decltype(jc)::value][i];
-    };
-    auto write_v = [&](auto jc, int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(vbuf0 + slot * TILEB + vlds[i]) = vreg[decltype(jc)::value][i];
-    };
-
-    // ---- LDS read bases (the images and fragment addressing of attn_fwd_kernel<64>) ----
-    int koff[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) koff[ks] = k_off<64>(r, 2 * ks + h);
-    constexpr int K_T_STRIDE = 32 * D * 2;
-    const int gl = lane & 15, q4 = gl >> 2, pp = gl & 3, g = (lane >> 4) & 1;
-    int voff[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        const int dcol = 32 * dt + 16 * g + 4 * pp;
-        voff[dt] = v_chunk_off<64>(4 * h + q4, dcol >> 3) + ((dcol & 7) << 1);
-    }
-    auto read_k = [&](const char* kb, int ks, bf16x8 (&kf)[2]) __attribute__((always_inline)) {
-#ifdef TCX_A4_NOLDS
-        if (ntiles > 0) return;
-#endif
-#pragma unroll
-        for (int t = 0; t < 2; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(kb + koff[ks] + t * K_T_STRIDE);
-    };
-    auto read_v = [&](const char* vb, int st, bf16x8 (&vf)[2]) __attribute__((always_inline)) {
-#ifdef TCX_A4_NOLDS
-        if (ntiles > 0) return;
-#endif
-        const int rowb = (32 * (st >> 1) + 16 * (st & 1)) * (D * 2);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            auto p0 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + rowb);
-            auto p1 = (__attribute__((address_space(3))) s16x4*)(vb + voff[dt] + rowb + 8 * (D * 2));
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0);
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p1);
-            vf[dt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        }
-    };
-
-    f32x16 o[2][2], lacc[2];                               // AGPRs: O^T[blk][dt], row sums
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[blk][0][i] = o[blk][1][i] = lacc[blk][i] = 0.f;
-    }
-    f32x16 sa[2][2], sb[2][2];                             // VGPRs: S^T of the current / next tile, [blk][t]
-    bf16x8 ones, pprev, kfa[2], kfb[2], vfa[2], vfb[2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { ones[j] = (__bf16)1.0f; pprev[j] = (__bf16)0.0f; }
-    asm volatile("" : "+a"(ones));                          // opaque + resident in AGPRs: never re-materialised next to an asm MFMA
-    vfa[0] = vfa[1] = vfb[0] = vfb[1] = pprev;
-
-    auto mask_tail = [&](f32x16 (&s)[2][2]) {              // keys >= Sk of the last tile
-        const int kv0 = (ntiles - 1) * 64 + 4 * h;
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (kv0 + 32 * t + (i & 3) + 8 * (i >> 2) >= Sk) s[blk][t][i] = -INFINITY;
-    };
-
-    // One slot (ST, BLK): exponentials of cur[BLK] for the 16 keys of step ST | the two QK^T MFMAs nxt[BLK][0..1] of k-step ST | PV +
-    // row-sum MFMAs of the PREVIOUS slot's P (its V fragments: vp).  5 MFMAs, 8 exp, 4 cvt.  One wave per SIMD: nothing hides a
-    // dependency stall, so (a) every v_cvt_pk packs the exponentials of the PREVIOUS gap (the transcendental's latency passes under
-    // an MFMA issue), (b) the P operand finished by the last convert of a slot is first read two MFMAs into the next slot (QK^T
-    // first) — except in slot (0, A), whose K fragments were only just requested: it runs P first behind an explicit s_nop 1 (the
-    // VALU -> MFMA-operand wait states hipcc cannot add around an asm statement).
-    auto slot = [&](auto has_next, auto stc, auto blkc, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], bf16x8 (&kf)[2], bf16x8 (&vp)[2])
-        __attribute__((always_inline)) {
-        constexpr bool NEXT = decltype(has_next)::value;
-        constexpr int ST = decltype(stc)::value, BLK = decltype(blkc)::value, QP = 1 - BLK;
-        constexpr int T = ST >> 1, S2 = ST & 1;
-        constexpr bool PFIRST = ST == 0 && BLK == 0;
-        u32x4 pw;
-        float e[8];
-#ifdef TCX_A4_NOEXP                    // timing-only ablations (wrong results): what each instruction class costs the single wave
-        auto ex = [&](int j) __attribute__((always_inline)) { e[j] = cur[BLK][T][8 * S2 + j]; asm volatile("" : "+v"(e[j])); };
-#else
-        auto ex = [&](int j) __attribute__((always_inline)) { e[j] = __builtin_amdgcn_exp2f(cur[BLK][T][8 * S2 + j]); };
-#endif
-        auto cv = [&](int j) __attribute__((always_inline)) {      // pack e[j], e[j + 1] here, in this gap
-            uint32_t w = pack_bf16(e[j], e[j + 1]);
-            asm volatile("" : "+v"(w));
-            pw[j >> 1] = w;
-        };
-        auto qk = [&](int t) __attribute__((always_inline)) {
-            if constexpr (NEXT) {
-                if constexpr (ST == 0) mf::s_first(nxt[BLK][t], kf[t], qf[BLK][ST]);
-                else mf::s_acc(nxt[BLK][t], kf[t], qf[BLK][ST]);
-            }
-        };
-        auto pv = [&](int which) __attribute__((always_inline)) {
-            if (which == 0) {
-                if constexpr (PFIRST) mf::o_acc_nop(o[QP][0], vp[0], pprev);
-                else mf::o_acc(o[QP][0], vp[0], pprev);
-            } else if (which == 1) mf::o_acc(o[QP][1], vp[1], pprev);
-            else {
-#ifndef TCX_A4_NOSUM
-                mf::l_acc(lacc[QP], ones, pprev);
-#endif
-            }
-        };
-        auto mm = [&](int gap) __attribute__((always_inline)) {    // the MFMA of gap 0..4
-            if constexpr (PFIRST) { if (gap < 3) pv(gap); else qk(gap - 3); }
-            else { if (gap < 2) qk(gap); else pv(gap - 2); }
-        };
-        mm(0); ex(0); ex(1);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(1); ex(2); ex(3); cv(0);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(2); ex(4); ex(5); cv(2);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(3); ex(6); ex(7); cv(4);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(4); cv(6);
-        __builtin_amdgcn_sched_barrier(0);
-        pprev = __builtin_bit_cast(bf16x8, pw);
-    };
-    // A tile: slots (0,A) (0,B) (1,A) ... (3,B).  V fragments of step ST (shared by both blocks) are read at the start of slot (ST, A)
-    // and used by slots (ST, B) and (ST + 1, A); K fragments of k-step ST + 1 are read at the start of slot (ST, B).
-    auto tile = [&](auto has_next, const char* kb, const char* vb, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2]) __attribute__((always_inline)) {
-        constexpr bool NEXT = decltype(has_next)::value;
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-        if constexpr (NEXT) read_k(kb, 0, kfa);
-        read_v(vb, 0, vfa);
-        slot(has_next, I0{}, I0{}, cur, nxt, kfa, vfb);          // (0,A): P of the previous tile's (3,B), V of its step 3 (vfb)
-        if constexpr (NEXT) read_k(kb, 1, kfb);
-        slot(has_next, I0{}, I1{}, cur, nxt, kfa, vfa);          // (0,B): P of (0,A), V of step 0
-        read_v(vb, 1, vfb);
-        slot(has_next, I1{}, I0{}, cur, nxt, kfb, vfa);          // (1,A): P of (0,B), V of step 0
-        if constexpr (NEXT) read_k(kb, 2, kfa);
-        slot(has_next, I1{}, I1{}, cur, nxt, kfb, vfb);          // (1,B): P of (1,A), V of step 1
-        read_v(vb, 2, vfa);
-        slot(has_next, I2{}, I0{}, cur, nxt, kfa, vfb);          // (2,A)
-        if constexpr (NEXT) read_k(kb, 3, kfb);
-        slot(has_next, I2{}, I1{}, cur, nxt, kfa, vfa);          // (2,B)
-        read_v(vb, 3, vfb);
-        slot(has_next, I3{}, I0{}, cur, nxt, kfb, vfa);          // (3,A)
-        slot(has_next, I3{}, I1{}, cur, nxt, kfb, vfb);          // (3,B)
-    };
-
-    constexpr std::integral_constant<int, 0> J0{};
-    constexpr std::integral_constant<int, 1> J1{};
-    auto one_tile = [&](auto masked, auto slot_k, auto slot_v, int t, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2]) __attribute__((always_inline)) {
-        tile(std::true_type{}, kbuf0 + decltype(slot_k)::value * TILEB, vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
-        if constexpr (decltype(masked)::value) {
-            if (t + 1 == ntiles - 1 && (Sk & 63)) mask_tail(nxt);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // ring / barrier structure of attn_fwd_kernel: tile t in slot t % R, a super-step = 2 tiles, one barrier.  (A 6-slot ring with the
-    // LDS writes between slots of the second tile and the next tile's first fragments requested ahead of the barrier was measured at
-    // the same cycle count, 1853 vs 1836 per tile, and spilled in its remainder code — spills next to asm MFMAs are unsafe, see the
-    // note at the kernel's head — so the simple form stays.)
-    auto super_step = [&](auto masked, auto ph, int t0) __attribute__((always_inline)) {
-        constexpr int PH = decltype(ph)::value;
-#if !defined(TCX_A4_NOSTAGE) && !defined(TCX_A4_NOLOADS)
-        load_k(J0, t0 + TPB + 1);
-        load_v(J0, t0 + TPB);
-        load_k(J1, t0 + TPB + 2);
-        load_v(J1, t0 + TPB + 1);
-#endif
-        one_tile(masked, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
-        one_tile(masked, std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa);
-#if !defined(TCX_A4_NOSTAGE) && !defined(TCX_A4_NOWRITES)
-        write_k(J0, (PH + TPB + 1) % R);
-        write_v(J0, (PH + TPB) % R);
-        write_k(J1, (PH + TPB + 2) % R);
-        write_v(J1, (PH + TPB + 1) % R);
-#endif
-#if !defined(TCX_A4_NOSTAGE) && !defined(TCX_A4_NOBAR)
-        __syncthreads();
-#endif
-    };
-    auto tail = [&](auto ph, int t0) __attribute__((always_inline)) {
-        constexpr int PH = decltype(ph)::value;
-        const int rem = (ntiles - 1) - t0;
-        if (rem == 1) {
-            one_tile(std::true_type{}, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb);
-            tile(std::false_type{}, kbuf0, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
-        } else {
-            tile(std::false_type{}, kbuf0, vbuf0 + (PH % R) * TILEB, sa, sb);
-        }
-    };
-
-    // prologue: K[0 .. 2], V[0 .. 1] into their slots, S(0) of both blocks
-    load_k(J0, 0);
-    load_v(J0, 0);
-    load_k(J1, 1);
-    load_v(J1, 1);
-    write_k(J0, 0);
-    write_v(J0, 0);
-    write_k(J1, 1);
-    write_v(J1, 1);
-    load_k(J0, TPB);
-    write_k(J0, TPB % R);
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        read_k(kbuf0, ks, kfa);
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (ks == 0) mf::s_first(sa[blk][t], kfa[t], qf[blk][ks]);
-                else mf::s_acc(sa[blk][t], kfa[t], qf[blk][ks]);
-            }
-    }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last QK^T MFMA has written S before anything reads it
-    if (ntiles == 1 && (Sk & 63)) mask_tail(sa);
-    __syncthreads();
-
-#ifdef TCX_ATTN_STAMP
-    const unsigned long long tC0 = __builtin_amdgcn_s_memtime(), tR0 = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
-    {
-        int t0 = 0;
-        for (; t0 + 2 * TPB < ntiles - 1; t0 += 2 * TPB) {   // steady state: never reaches the last key tile -> no mask code
-            super_step(std::false_type{}, std::integral_constant<int, 0>{}, t0);
-            super_step(std::false_type{}, std::integral_constant<int, TPB>{}, t0 + TPB);
-        }
-        if (t0 + 2 * TPB <= ntiles - 1) {
-            super_step(std::true_type{}, std::integral_constant<int, 0>{}, t0);
-            super_step(std::true_type{}, std::integral_constant<int, TPB>{}, t0 + TPB);
-            t0 += 2 * TPB;
-        }
-        if (t0 + TPB <= ntiles - 1) {
-            super_step(std::true_type{}, std::integral_constant<int, 0>{}, t0);
-            tail(std::integral_constant<int, TPB>{}, t0 + TPB);
-        } else {
-            tail(std::integral_constant<int, 0>{}, t0);
-        }
-    }
-#ifdef TCX_ATTN_STAMP
-    {
-        const unsigned long long tC1 = __builtin_amdgcn_s_memtime(), tR1 = __builtin_amdgcn_s_memrealtime();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        if ((blockIdx.x % 997 == 5) && lane == 0 && (wave == 0 || wave == 3))
-            printf("ASTAMP body 4 D 64 wg %d wave %d tiles %d cycles %llu real %llu\n", (int)blockIdx.x, wave, ntiles, tC1 - tC0, tR1 - tR0);
-    }
-#endif
-    // the delayed PV / row-sum product of the very last slot (3, B): V of step 3 = vfb
-    mf::o_acc_nop(o[1][0], vfb[0], pprev);
-    mf::o_acc(o[1][1], vfb[1], pprev);
-    mf::l_acc(lacc[1], ones, pprev);
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // let the last MFMA retire before the accumulators are read
-
-    // ---- epilogue ----
-    float l[2];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) l[blk] = lacc[blk][0];   // every row of ones . P^T holds the row sums (both half-waves' keys)
-    if (part >= 0) {
-        const uint32_t items = p.split * (p.nwg - p.n_full);
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            float* wo = p.ws + ((size_t)item * 256 + wave * 64 + 32 * blk + r) * D;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<f32x4*>(wo + 32 * dt + 8 * i + 4 * h) = f32x4{o[blk][dt][4 * i], o[blk][dt][4 * i + 1], o[blk][dt][4 * i + 2], o[blk][dt][4 * i + 3]};
-            if (h == 0) p.ws[attn_ws_o_floats(items, D) + (size_t)item * 256 + wave * 64 + 32 * blk + r] = l[blk];
-        }
-        return;
-    }
-    constexpr int RB = D * 2;
-    __syncthreads();                                       // every wave is past its last K / V fragment read
-    char* ot = smem + wave * (64 * RB);                    // 64 rows x 128 B; 16-byte chunk c of row q at c ^ (q & 7)
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        const float inv = 1.0f / l[blk];
-        const int row = 32 * blk + r;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int d0 = 32 * dt + 8 * i + 4 * h;
-                u32x2 w;
-                w[0] = pack_bf16(o[blk][dt][4 * i] * inv, o[blk][dt][4 * i + 1] * inv);
-                w[1] = pack_bf16(o[blk][dt][4 * i + 2] * inv, o[blk][dt][4 * i + 3] * inv);
-                *reinterpret_cast<u32x2*>(ot + row * RB + (((d0 >> 3) ^ (row & 7)) << 4) + ((d0 & 4) << 1)) = w;
-            }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int rl = lane >> 3, ch = lane & 7;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = i * 8 + rl;
-        const u32x4 val = *reinterpret_cast<const u32x4*>(ot + row * RB + ((ch ^ (row & 7)) << 4));
-        const int qr = q0 + row;
-        if (qr < p.Sq)
-            *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.osb + (int64_t)qr * p.oss + (int64_t)hd * p.osh + 8 * ch) = val;
     }
 }
 
@@ -1583,23 +743,7 @@ int launch_one(AttnParams p, hipStream_t st) {
             grid = p.n_full + sp.tail * sp.split;
         }
     }
-    bool body16 = false;
-    if constexpr (BOUND && !F32 && D == 64 && NW == 8) {
-        if (p.body16 == 2 && p.proven) {                     // 4 waves x 64 rows: same grid, same LDS size, same workspace layout
-            static TcxPerDeviceOnce lds_attr4;
-            const int rc4 = tcx_ensure_dynamic_lds(lds_attr4, reinterpret_cast<const void*>(&attn_fwd4_kernel), lds, "tcx_attn_fwd");
-            if (rc4 != TCX_OK) return rc4;
-            hipLaunchKernelGGL(attn_fwd4_kernel, dim3(grid), dim3(256), lds, st, p);
-            body16 = true;
-        } else if (p.body16 && p.proven) {                   // 16x16x32 body: same grid, same LDS size, same workspace layout
-            static TcxPerDeviceOnce lds_attr16;
-            const int rc16 = tcx_ensure_dynamic_lds(lds_attr16, reinterpret_cast<const void*>(&attn_fwd16_kernel), lds, "tcx_attn_fwd");
-            if (rc16 != TCX_OK) return rc16;
-            hipLaunchKernelGGL(attn_fwd16_kernel, dim3(grid), dim3(512), lds, st, p);
-            body16 = true;
-        }
-    }
-    if (!body16) hipLaunchKernelGGL((attn_fwd_kernel<D, F32, FAST, NW, BOUND>), dim3(grid), dim3(64 * NW), lds, st, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, F32, FAST, NW, BOUND>), dim3(grid), dim3(64 * NW), lds, st, p);
     if constexpr (BOUND && !F32 && D == 64 && NW == 8) {
         if (p.split > 1) hipLaunchKernelGGL(attn_combine_kernel, dim3((p.nwg - p.n_full) * 16), dim3(256), 0, st, p);
     }
@@ -1643,7 +787,7 @@ extern "C" int tcx_attn_fwd_ws(const void* q, const void* k, const void* v, void
                                void* workspace, int64_t workspace_bytes, void* stream) {
     TCX_CHECK(workspace == nullptr || (tcx_aligned16(workspace) && workspace_bytes >= 0), TCX_E_ALIGN, "tcx_attn_fwd: workspace must be 16-byte aligned");
     TCX_CHECK(q && k && v && o, TCX_E_NULL, "tcx_attn_fwd: null pointer");
-    TCX_CHECK((flags & ~(TCX_ATTN_LOG2_SCORES | TCX_ATTN_BOUND_PROVEN | TCX_ATTN_BODY_16X16X32 | TCX_ATTN_BODY_4WAVE)) == 0, TCX_E_SHAPE, "tcx_attn_fwd: unknown flags 0x%x", flags);
+    TCX_CHECK((flags & ~(TCX_ATTN_LOG2_SCORES | TCX_ATTN_BOUND_PROVEN)) == 0, TCX_E_SHAPE, "tcx_attn_fwd: unknown flags 0x%x", flags);
     const bool log2s = (flags & TCX_ATTN_LOG2_SCORES) != 0;
     TCX_CHECK(!(flags & TCX_ATTN_BOUND_PROVEN) || (log2s && k_sqmax), TCX_E_SHAPE,
               "tcx_attn_fwd: TCX_ATTN_BOUND_PROVEN needs TCX_ATTN_LOG2_SCORES and k_sqmax");
@@ -1671,7 +815,6 @@ extern "C" int tcx_attn_fwd_ws(const void* q, const void* k, const void* v, void
     p.nqb = 0; p.nwg = 0;       // set per launch geometry
     p.ws = (float*)workspace; p.ws_bytes = workspace ? (size_t)workspace_bytes : 0; p.n_full = 0; p.split = 1;
     p.proven = (flags & TCX_ATTN_BOUND_PROVEN) ? 1u : 0u;
-    p.body16 = (flags & TCX_ATTN_BODY_4WAVE) ? 2u : (flags & TCX_ATTN_BODY_16X16X32) ? 1u : 0u;
     hipStream_t s = (hipStream_t)stream;
     if (D == 64 && log2s) return out_dtype == TCX_F32 ? launch<64, true, true>(p, s) : launch<64, false, true>(p, s);
     if (D == 64) return out_dtype == TCX_F32 ? launch<64, true, false>(p, s) : launch<64, false, false>(p, s);

@@ -179,13 +179,9 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(const ConvGemmParams p) 
                 if (ci0 >= p.Cin) {                      // wave-uniform branch, every Cin / 64 K-tiles: next tap
                     ci0 = 0;
                     if (++tap_dx == p.kW) { tap_dx = 0; if (++tap_dy == p.kH) { tap_dy = 0; ++tap_dt; } }
-#ifndef TCX_CONV_EXP_NOTAP            // timing experiments only (wrong results): what a tap change costs
                     g_nxt = tap_pointer();
-#ifndef TCX_CONV_EXP_NOREFRESH
                     refresh_rows(IC<0>{});
                     tap_changed = true;
-#endif
-#endif
                 }
             }
         }

@@ -113,9 +113,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
     }
     auto stage = [&](auto hsel, int buf, int kt) __attribute__((always_inline)) {
         constexpr int H = decltype(hsel)::value;                        // 0 X0, 1 X1, 2 W0, 3 W1
-#ifndef TCX_GEMM_EXP_PEEL
         kt = kt < KT ? kt : KT - 1;
-#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const uint16_t* src = (H < 2 ? px[H & 1][j] : pw[H & 1][j]) + (int64_t)kt * BK;
@@ -161,9 +159,6 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
     };
     auto mfma_quadrant = [&](auto qmsel, auto qnsel) __attribute__((always_inline)) {
         constexpr int QM = decltype(qmsel)::value, QN = decltype(qnsel)::value;
-#ifdef TCX_GEMM_EXP_PRIO               // s_setprio(1) around the MFMA cluster: measured -0.5..-1 % here, off
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -172,9 +167,6 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
                 for (int u = 0; u < 2; ++u)
                     acc[QM * 4 + tt][QN * 2 + u] =
                         __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][ks], xf[tt][ks], acc[QM * 4 + tt][QN * 2 + u], 0, 0, 0);
-#ifdef TCX_GEMM_EXP_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
     };
     // one phase: P = 0..7 (P >> 2 = buffer being computed), kt2 = even K-tile of this iteration
     // LAST = the tile's last iteration: only phase 0 still has something to stage (W half 0 of the odd K-tile); nothing
@@ -200,9 +192,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
         TCX_SB();
         if constexpr (Q == 3 && !LAST) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         if constexpr (P == 3 && LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifndef TCX_GEMM_EXP_LGKM_AFTER      // timing experiment only: reads may still be in flight when the partner re-stages
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         TCX_SB();
@@ -227,9 +217,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-#ifndef TCX_GEMM_EXP_NOSTAGGER
     if (wr == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs one barrier behind
-#endif
     TCX_SB();
 
     auto iteration = [&](auto lastsel, int kt2) __attribute__((always_inline)) {
@@ -242,18 +230,11 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
         phase(std::integral_constant<int, 6>{}, lastsel, kt2);
         phase(std::integral_constant<int, 7>{}, lastsel, kt2);
     };
-#ifdef TCX_GEMM_EXP_PEEL               // peeled last iteration (no loads past the end of K): measured 2-4 % SLOWER, off
-    for (int kt2 = 0; kt2 < KT - 2; kt2 += 2) iteration(std::false_type{}, kt2);
-    iteration(std::true_type{}, KT - 2);
-#else
     // every iteration stages; past the end of K the last one re-loads the last K-tile into buffers nobody reads again
     // (keeps the vmcnt counts, 7 half-tiles of extra L2 traffic per tile) and the loads are drained here
     for (int kt2 = 0; kt2 < KT; kt2 += 2) iteration(std::false_type{}, kt2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing LDS-DMA must land before the LDS is released
-#endif
-#ifndef TCX_GEMM_EXP_NOSTAGGER
     if (wr == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count
-#endif
     // A wave's vmcnt(0) covers only its OWN trailing LDS-DMA, whose pieces land in other waves' epilogue tiles (lds + wid * 16 KiB
     // spans both K-tile buffers): every wave must have drained before any wave writes its tile.
     __builtin_amdgcn_s_barrier();
@@ -291,18 +272,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
         // residual: all of the lane's vectors in flight at once (the fragment registers of the main loop are free now).
         // Default: fetched ROW-WISE (16 instructions of 8 rows x 128 B, 16 bytes per lane) into the wave's LDS tile, the
         // same image the result is written back through, and picked up from there in the accumulator layout.
-#if defined(TCX_GEMM_EXP_DIRECT_STORE) || defined(TCX_GEMM_EXP_DIRECT_RES)
-        u32x2 rv[8][4];
-#endif
         if constexpr (EPI == 2) {
-#if defined(TCX_GEMM_EXP_DIRECT_STORE) || defined(TCX_GEMM_EXP_DIRECT_RES)
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const uint16_t* rrow = p.res + (int64_t)bb[a] * p.res_stride_b + (int64_t)rbb[a] * p.ldres;
-#pragma unroll
-                for (int bq = 0; bq < 4; ++bq) rv[a][bq] = *reinterpret_cast<const u32x2*>(rrow + ncol[bq]);
-            }
-#else
             {
                 const int rl = lane >> 3, ch = lane & 7;
                 int nc8 = n0 + wc * 64 + ch * 8;
@@ -323,13 +293,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile now holds the residual; each element is read
             }                                                        // and then overwritten with its result by the same lane
-#endif
         }
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-#ifdef TCX_GEMM_EXP_DIRECT_STORE
-            uint16_t* yrow = p.y + (int64_t)bb[a] * p.y_stride_b + (int64_t)rbb[a] * p.ldy;
-#endif
             u32x2 gv[4];
             if constexpr (EPI == 2 && GATED) {
                 const uint16_t* gate = (rbb[a] < (uint32_t)p.text_len ? p.gate_t : p.gate_v) + (int64_t)bb[a] * p.gate_stride_b;
@@ -346,12 +312,8 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
                     for (int j = 0; j < 4; ++j) v[j] = gelu_tanh_f(v[j]);
                 }
                 if constexpr (EPI == 2) {
-#if defined(TCX_GEMM_EXP_DIRECT_STORE) || defined(TCX_GEMM_EXP_DIRECT_RES)
-                    const u32x2 rvv = rv[a][bq];
-#else
                     const u32x2 rvv = *reinterpret_cast<const u32x2*>(lds + wid * 16384 + (a * 16 + fi) * 128 +
                                                                       (((bq * 2 + (fg >> 1)) ^ ((a * 16 + fi) & 7)) << 4) + ((fg & 1) << 3));
-#endif
                     const float r[4] = {bf16lo(rvv[0]), bf16hi(rvv[0]), bf16lo(rvv[1]), bf16hi(rvv[1])};
                     if constexpr (GATED) {
                         const float gg[4] = {bf16lo(gv[bq][0]), bf16hi(gv[bq][0]), bf16lo(gv[bq][1]), bf16hi(gv[bq][1])};
@@ -365,17 +327,12 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
                 u32x2 o;
                 o[0] = pack_bf16(v[0], v[1]);
                 o[1] = pack_bf16(v[2], v[3]);
-#ifdef TCX_GEMM_EXP_DIRECT_STORE
-                if (mok[a] && nok[bq]) *reinterpret_cast<u32x2*>(yrow + ncol[bq]) = o;
-#else
                 // through the wave's own 16 KiB of LDS (128 rows x 128 B; the main loop's buffers are free: every wave is past
                 // its last fragment read after the final barrier): 16-byte chunk c of row r sits at chunk c ^ (r & 7)
                 const int row = a * 16 + fi, chunk = bq * 2 + (fg >> 1);
                 *reinterpret_cast<u32x2*>(lds + wid * 16384 + row * 128 + ((chunk ^ (row & 7)) << 4) + ((fg & 1) << 3)) = o;
-#endif
             }
         }
-#ifndef TCX_GEMM_EXP_DIRECT_STORE
         (void)mok;
         // read back row-wise: one instruction = 8 rows x 128 B, full cache lines, 16-byte stores (the direct form was 32 stores
         // of 8 bytes per lane, each instruction touching 16 rows x 32 B: store-issue bound)
@@ -393,7 +350,6 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmParams p) {
                 *reinterpret_cast<u32x4*>(p.y + (int64_t)b * p.y_stride_b + (int64_t)rb * p.ldy + ncol8) = val;
             }
         }
-#endif
     };
     if (EPI == 2 && p.gate_v) store_rows(std::true_type{});
     else store_rows(std::false_type{});

@@ -92,97 +92,6 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const LnParams p) {
 // registers (raw bf16), walks RPW rows of one segment (batch item x {text, video}: one modulation) and has the next row's
 // loads in flight while it reduces and writes the current one.  Same arithmetic, same order.
 
-template <int NCH>
-__global__ __launch_bounds__(256) void ln_modulate_rows_kernel(const LnParams p) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int b = blockIdx.y >> 1, vid = blockIdx.y & 1;
-    const int seg0 = vid ? p.text_len : 0, seg1 = vid ? p.rows : p.text_len;
-    const int r0 = seg0 + (int)blockIdx.x * (4 * p.rows_per_wave) + wv;     // this wave: r0, r0 + 4, ...
-    if (r0 >= seg1) return;
-    const int nchunk = p.C >> 3;
-    const uint16_t* sh = vid ? p.shift_v : p.shift_t;
-    const uint16_t* sc = vid ? p.scale_v : p.scale_t;
-    if (sh) sh += (int64_t)b * p.msb;
-    if (sc) sc += (int64_t)b * p.msb;
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    u32x4 pg[NCH], pb[NCH], ps[NCH], pt[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const int ch = j * 64 + lane;
-        const bool ok = ch < nchunk;
-        pg[j] = (ok && p.gamma) ? *reinterpret_cast<const u32x4*>(p.gamma + 8 * ch) : zero4;
-        pb[j] = (ok && p.beta) ? *reinterpret_cast<const u32x4*>(p.beta + 8 * ch) : zero4;
-        ps[j] = (ok && sc) ? *reinterpret_cast<const u32x4*>(sc + 8 * ch) : zero4;
-        pt[j] = (ok && sh) ? *reinterpret_cast<const u32x4*>(sh + 8 * ch) : zero4;
-    }
-    const uint16_t* xb = p.x + (int64_t)b * p.xsb;
-    uint16_t* yb = p.y + (int64_t)b * p.ysb;
-    u32x4 raw[NCH], nraw[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const int ch = j * 64 + lane;
-        raw[j] = ch < nchunk ? *reinterpret_cast<const u32x4*>(xb + (int64_t)r0 * p.C + 8 * ch) : zero4;
-    }
-    const float invC = 1.0f / (float)p.C;
-    for (int i = 0; i < p.rows_per_wave; ++i) {
-        const int r = r0 + 4 * i;
-        if (r >= seg1) break;
-        const bool more = i + 1 < p.rows_per_wave && r + 4 < seg1;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int ch = j * 64 + lane;
-            nraw[j] = (more && ch < nchunk) ? *reinterpret_cast<const u32x4*>(xb + (int64_t)(r + 4) * p.C + 8 * ch) : zero4;
-        }
-        // x and the parameters stay packed (raw bf16) in registers and are unpacked where used: holding them as floats
-        // (or letting the compiler hoist the parameter unpack out of the row loop) costs 200+ VGPRs and the occupancy
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            float v[8];
-            unpack8(raw[j], v);                          // chunks past the row are zero: they add nothing to the sums
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sum += v[e];
-        }
-        const float mean = wave_sum(sum) * invC;
-        float sq = 0.f;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            if (j * 64 + lane < nchunk) {
-                float v[8];
-                unpack8(raw[j], v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float d = v[e] - mean;
-                    sq += d * d;
-                }
-            }
-        }
-        const float rstd = rsqrtf(wave_sum(sq) * invC + p.eps);
-        uint16_t* yr = yb + (int64_t)r * p.C;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int ch = j * 64 + lane;
-            if (ch < nchunk) {
-                asm volatile("" : "+v"(pg[j]), "+v"(pb[j]), "+v"(ps[j]), "+v"(pt[j]));   // keep the unpack inside the loop
-                float v[8], g[8], be[8], s1[8], s2[8], out[8];
-                unpack8(raw[j], v);
-                unpack8(pg[j], g); unpack8(pb[j], be); unpack8(ps[j], s1); unpack8(pt[j], s2);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float t = (v[e] - mean) * rstd;
-                    if (p.gamma) t *= g[e];
-                    if (p.beta) t += be[e];
-                    if (sc) t *= (1.0f + s1[e]);
-                    if (sh) t += s2[e];
-                    out[e] = t;
-                }
-                *reinterpret_cast<u32x4*>(yr + 8 * ch) = pack8(out);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) raw[j] = nraw[j];
-    }
-}
 
 // Round 3: the row-looping kernel with the modulation folded ONCE per workgroup into two fp32 vectors in LDS,
 //     A = gamma (1 + scale),   Bc = beta (1 + scale) + shift        =>   y = ((x - mean) rstd) A + Bc,
@@ -521,17 +430,10 @@ extern "C" int tcx_layernorm_modulate(const void* x, void* y, int32_t B, int32_t
         // parameter set-up per workgroup is cheap enough to repeat every 8 rows.  (The round-2 register-parameter kernel at 8 rows:
         // 0.112 ms; sizing IT to one resident round had measured 11 % slower.)
         const int seg = tl > rows - tl ? tl : rows - tl;
-#ifdef TCX_NORM_EXP_RPW
-        const int64_t rpw = TCX_NORM_EXP_RPW;
-#elif defined(TCX_NORM_EXP_REGPARAMS)
-        const int64_t rpw = 8;
-#else
         const int64_t rpw = 2;
-#endif
         p.rows_per_wave = (int32_t)rpw;
         const int per_block = 4 * (int)rpw;
         dim3 g2((unsigned)((seg + per_block - 1) / per_block), (unsigned)(2 * B));
-#ifndef TCX_NORM_EXP_REGPARAMS         // A/B builds only: the round-2 kernel with the four parameter vectors in registers
         {
             const size_t lds = (size_t)C * 8;            // A and Bc as fp32: 24 KiB at C = 3072 (< the 64 KiB default limit up to C = 8192)
             if (nch <= 2) hipLaunchKernelGGL(ln_modulate_lds_kernel<2>, g2, block, lds, st, p);
@@ -539,11 +441,6 @@ extern "C" int tcx_layernorm_modulate(const void* x, void* y, int32_t B, int32_t
             else hipLaunchKernelGGL(ln_modulate_lds_kernel<6>, g2, block, lds, st, p);
             TCX_LAUNCH_RET();
         }
-#endif
-        if (nch <= 2) hipLaunchKernelGGL(ln_modulate_rows_kernel<2>, g2, block, 0, st, p);
-        else if (nch <= 4) hipLaunchKernelGGL(ln_modulate_rows_kernel<4>, g2, block, 0, st, p);
-        else hipLaunchKernelGGL(ln_modulate_rows_kernel<6>, g2, block, 0, st, p);
-        TCX_LAUNCH_RET();
     }
     if (nch <= 1) hipLaunchKernelGGL(ln_modulate_kernel<1>, grid, block, 0, st, p);
     else if (nch <= 2) hipLaunchKernelGGL(ln_modulate_kernel<2>, grid, block, 0, st, p);
@@ -584,9 +481,6 @@ extern "C" int tcx_qk_layernorm_rope(void* q, void* k, int32_t B, int32_t S, int
         // per-batch rounding: blocks are per batch item (blockIdx.y), 4 waves each
         while (tpw < S && (int64_t)B * ((S + 4 * tpw - 1) / (4 * tpw)) * 4 > resident_waves) ++tpw;
         if (tpw < 8) tpw = 8;
-#ifdef TCX_NORM_EXP_FIXED8
-        tpw = 8;
-#endif
         p.tokens_per_wave = (int32_t)tpw;
         const int per_block = 4 * (int)tpw;
         hipLaunchKernelGGL(qk_ln_rope_tok_kernel<6>, dim3((unsigned)((S + per_block - 1) / per_block), (unsigned)B), dim3(256), 0,

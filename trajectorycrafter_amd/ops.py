@@ -56,17 +56,9 @@ def attn_timing_stop() -> dict:
     return {d: {"n": len(ev), "ms": float(sum(a.elapsed_time(b) for a, b in ev))} for d, ev in rec.items()}
 
 
-# Which MFMA body the bound-proven D = 64 self-attention runs.  Round-3 A/B: the 16x16x32 body needs 13 % more cycles
-# and holds a 14-17 % higher clock — standalone (attention back to back) it is 3.7 % faster (6.58 vs 6.83 ms), inside the full
-# denoising step, where GEMMs share the power budget, 3.8 % SLOWER (7.27 vs 7.00 ms, tools/step_ab.py, 6 interleaved blocks) on one
-# box and +-1 % on another.  The product keeps the body whose result does not depend on clock headroom.
-ATTN_BODY16_DEFAULT = False
-
-
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
              out: Optional[torch.Tensor] = None, out_dtype=BF16, log2_scores: bool = False,
-             k_sqmax: Optional[torch.Tensor] = None, split_tail: bool = True, bound_proven: bool = False,
-             body16: Optional[bool] = None) -> torch.Tensor:
+             k_sqmax: Optional[torch.Tensor] = None, split_tail: bool = True, bound_proven: bool = False) -> torch.Tensor:
     """q [B,Sq,H,D], k/v [B,Sk,H,D] bf16 views -> o [B,Sq,H,D].
 
     log2_scores: q k^T already is the base-2 exponent (q pre-multiplied by scale*log2(e)); scale must be 1.
@@ -74,9 +66,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
     split_tail: let the bound-centred D = 64 launch split its last partly filled round of workgroups along the keys
     (needs a scratch buffer, allocated here; False = the single-pass launch, for A/B runs and tests).
     bound_proven: the caller guarantees |q_row| * sqrt(k_sqmax) * 1.002 + 1e-3 < 60 for every row (TCX_ATTN_BOUND_PROVEN): no
-    per-workgroup test, no launch of the exact kernel on the complement.
-    body16: with bound_proven, D = 64, bf16 out: the v_mfma_f32_16x16x32_bf16 loop body (TCX_ATTN_BODY_16X16X32); None = the
-    module default `ATTN_BODY16_DEFAULT`."""
+    per-workgroup test, no launch of the exact kernel on the complement."""
     for n, t in (("q", q), ("k", k), ("v", v)):
         _need(t, n)
     B, Sq, H, D = q.shape
@@ -95,11 +85,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
     if _ATTN_TIMING is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    if body16 is None:
-        body16 = ATTN_BODY16_DEFAULT
-    flags = ((_lib.TCX_ATTN_LOG2_SCORES if log2_scores else 0) | (_lib.TCX_ATTN_BOUND_PROVEN if bound_proven else 0) |
-             ((_lib.TCX_ATTN_BODY_4WAVE if body16 == 4 else _lib.TCX_ATTN_BODY_16X16X32)
-              if (body16 and bound_proven and D == 64 and out_dtype == BF16) else 0))        # body16: False | True (16x16x32) | 4 (4-wave)
+    flags = (_lib.TCX_ATTN_LOG2_SCORES if log2_scores else 0) | (_lib.TCX_ATTN_BOUND_PROVEN if bound_proven else 0)
     odt = TCX_F32 if out_dtype == torch.float32 else TCX_BF16
     # scratch of the tail split (balances the last, partly filled round of workgroups; include/tcx_hip.h): caller-owned
     ws_bytes = int(lib.tcx_attn_fwd_workspace_bytes(B, H, Sq, Sk, D, flags, int(k_sqmax is not None), odt)) if split_tail else 0
