@@ -213,8 +213,8 @@ def test_pipeline_stochastic_ddim_eta(setup):
     dpm = TrajCrafter_Pipeline(None, None, s["pipe"].vae, s["pipe"].transformer, S.DPMSolverMultistepScheduler())
     assert torch.equal(dpm(output_type="latent", eta=0.6, **kw).videos, dpm(output_type="latent", **kw).videos)
     cog = TrajCrafter_Pipeline(None, None, s["pipe"].vae, s["pipe"].transformer, S.CogVideoXDDIMScheduler())
-    with pytest.raises(NotImplementedError, match="DDIM_Origin"):
-        cog(output_type="latent", eta=0.6, **kw)
+    # DDIM_Cog: the library's step has the `eta` parameter and never reads it (the reference pipeline runs): accepted, no effect
+    assert torch.equal(cog(output_type="latent", eta=0.6, **kw).videos, cog(output_type="latent", **kw).videos)
 
 
 def test_pipeline_helper_methods(setup):
@@ -332,8 +332,8 @@ def test_pipeline_other_samplers_match_oracle(setup, name):
     ddim = s["pipe"](output_type="latent", **kw).videos
     assert not torch.equal(lat, ddim)
     assert torch.equal(pipe(output_type="latent", generator=torch.Generator(device=dev).manual_seed(21), **kw).videos, lat)
-    if name == "PNDM":               # a shortened PNDM schedule would start inside the Runge-Kutta phase: the stateful schedule refuses it
-        with pytest.raises(ValueError, match="expects timestep"):
+    if name == "PNDM":               # a shortened PNDM schedule would start inside the Runge-Kutta phase: refused up front, by name
+        with pytest.raises(NotImplementedError, match="PNDM sampler is not built"):
             pipe(**dict({k: v for k, v in kw.items() if k != "latents"}, strength=0.5, video=tp["video"]))
         return
     # strength < 1 with this sampler: the last 2 of 4 steps from the noised video latents (scheduler.add_noise in the latent dtype)

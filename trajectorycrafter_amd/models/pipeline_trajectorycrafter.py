@@ -522,6 +522,10 @@ class TrajCrafter_Pipeline:
             raise ValueError(f"`eta` must be in [0, 1], got {eta}")
         if not 0.0 < strength <= 1.0:
             raise ValueError(f"`strength` must be in (0, 1], got {strength}")
+        if strength < 1.0 and type(self.scheduler).__name__ == "PNDMScheduler":
+            raise NotImplementedError("`strength` < 1 with the PNDM sampler is not built: its schedule is stateful (12 Runge-Kutta evaluations "
+                                      "first) and the shortened loop of :664-671 would enter it mid-way; use DDIM_Origin / DDIM_Cog / Euler / "
+                                      "Euler A / DPM++ for strength < 1")
         num_videos_per_prompt = 1
         if hasattr(self.transformer, "clear_cross_kv_cache"):
             self.transformer.clear_cross_kv_cache()               # opt-in K / V reuse (model.cache_cross_kv) never outlives a clip

@@ -163,8 +163,10 @@ class CogVideoXDDIMScheduler(DDIMScheduler):
 
     def fused_cfg_step(self, uncond, cond, sample, guidance: float, timestep: int, generator=None, eta: float = 0.0) -> torch.Tensor:
         from . import ops
-        if eta != 0.0:
-            raise NotImplementedError("eta > 0 is built for 'DDIM_Origin' (scheduler.DDIMScheduler) only")
+        # The library's `CogVideoXDDIMScheduler.step` HAS an `eta` parameter (so the reference pipeline forwards its `eta` to it,
+        # :521-540) and never reads it: the update is the deterministic `a x + b x0` form whatever eta is.  Same here: accepted
+        # and unused (round 3 refused a non-zero value; the reference would have run).
+        del eta
         sa, sb, ca, cb = self.step_coeffs(timestep)
         return ops.cfg_ddim_cog_step(uncond, cond, sample, guidance, sa, sb, ca, cb)
 
