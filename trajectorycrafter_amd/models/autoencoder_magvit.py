@@ -7,8 +7,9 @@ kernel `tcx_conv3d_cl` (causal temporal context, spatial zero padding, nearest x
 temporal frame map are folded into its gather, so no padded / upsampled tensor is materialised),
 GroupNorm + SpatialNorm + SiLU is one two-pass fused kernel pair, residual adds are conv epilogues.
 
-The nn.Conv3d / nn.Conv2d / nn.GroupNorm sub-modules only hold parameters; there is no torch
-fallback — CPU or non-bf16 calls raise `TcxError`.
+Every sub-module also has the reference's own `forward(...)` signature on [N, C, T, H, W] tensors (same kernels behind a
+layout conversion; tests/test_signatures.py compares the signatures with the imported reference's).  The leaf nn.Conv2d /
+nn.GroupNorm modules only hold parameters; there is no torch fallback — CPU or non-bf16 calls raise `TcxError`.
 """
 from __future__ import annotations
 
