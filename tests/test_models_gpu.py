@@ -77,6 +77,12 @@ def _check_deep(got, contract, exact, what, record=True, mean_x=1.15, p999_x=1.3
     assert float(e_hip.mean()) <= mean_x * float(e_con.mean()) + 1e-5, msg
     if exact.numel() < 65536:                  # the 99.9th percentile of a small tensor is the tail of < 65 elements: r4 records reach 1.26 x
         p999_x = max(p999_x, 1.5)
+    # sampling noise of the two mean ratios: |error| is roughly exponential (coefficient of variation ~ 1), so the ratio of two means over
+    # n elements has a relative standard deviation of about sqrt(2 / n); four of those are granted on top of the factor.  Nothing for a
+    # full-size tensor (n = 1e8: 6e-4), 0.03 at the default-width cases (n = 37 k), 0.18 for a 960-element latent — the round-4 deep
+    # fuzz sweeps (5 500 cases) tripped the bare 1.15 twice, at 1.156 and 1.162, both on 960-element outputs
+    slack = 4.0 * (2.0 / max(exact.numel(), 1)) ** 0.5
+    mean_x, hc_x = mean_x + slack, hc_x + slack
     assert q(e_hip) <= p999_x * q(e_con) + 1e-4, msg
     assert float(e_hc.mean()) <= hc_x * float(e_con.mean()) + 1e-5, msg
     return rec
