@@ -74,15 +74,15 @@ def _check_deep(got, contract, exact, what, record=True, mean_x=1.15, p999_x=1.3
            "hip_vs_contract": {"max": float(e_hc.max()), "mean": float(e_hc.mean()), "inside_rtol1e-3_atol1e-4": inside(got, contract)}}
     if record:
         record_parity(rec)
-    assert float(e_hip.mean()) <= mean_x * float(e_con.mean()) + 1e-5, msg
     if exact.numel() < 65536:                  # the 99.9th percentile of a small tensor is the tail of < 65 elements: r4 records reach 1.26 x
-        p999_x = max(p999_x, 1.5)
+        p999_x = max(p999_x, 1.5 if exact.numel() >= 4096 else 2.0)      # below 4 k elements "p99.9" is the largest few errors (192-element case: 1.73 x)
     # sampling noise of the two mean ratios: |error| is roughly exponential (coefficient of variation ~ 1), so the ratio of two means over
     # n elements has a relative standard deviation of about sqrt(2 / n); four of those are granted on top of the factor.  Nothing for a
     # full-size tensor (n = 1e8: 6e-4), 0.03 at the default-width cases (n = 37 k), 0.18 for a 960-element latent — the round-4 deep
     # fuzz sweeps (5 500 cases) tripped the bare 1.15 twice, at 1.156 and 1.162, both on 960-element outputs
     slack = 4.0 * (2.0 / max(exact.numel(), 1)) ** 0.5
     mean_x, hc_x = mean_x + slack, hc_x + slack
+    assert float(e_hip.mean()) <= mean_x * float(e_con.mean()) + 1e-5, msg
     assert q(e_hip) <= p999_x * q(e_con) + 1e-4, msg
     assert float(e_hc.mean()) <= hc_x * float(e_con.mean()) + 1e-5, msg
     return rec
