@@ -518,7 +518,7 @@ def run_rank(args):
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         fwd_flop = {(49, 480, 720): 3.5585e14, (49, 384, 672): 2.3387e14}.get((args.frames, args.height, args.width))
         traffic, traffic_src = None, None
-        for name in ("r3_attn_pmc.json", "r2_attn_pmc.json", "r1_attn_pmc.json"):   # PMC counters cannot be read inside the timed run: committed
+        for name in ("r4_attn_pmc.json", "r3_attn_pmc.json", "r2_attn_pmc.json", "r1_attn_pmc.json"):   # PMC counters cannot be read inside the timed run: committed
             pmc = os.path.join(ROOT, "profiles", name)          # rocprofv3 --pmc result of the same kernel and shape
             if os.path.exists(pmc) and (args.frames, args.height, args.width) == (49, 480, 720):
                 with open(pmc) as f:

@@ -450,3 +450,25 @@ def test_pndm_schedule_and_coefficients_match_oracle():
     x0, nz = torch.randn(1, 3, 16, 4, 6, generator=g).to(torch.bfloat16), torch.randn(1, 3, 16, 4, 6, generator=g).to(torch.bfloat16)
     ddim_like = DDIMScheduler(rescale_betas_zero_snr=False)
     assert torch.equal(a.add_noise(x0, nz, torch.tensor([499])), ddim_like.add_noise(x0, nz, torch.tensor([499])))
+
+
+def test_hashed_weight_stream_known_answers():
+    """`init_weights.hashed_normal` / `hashed_state_dict` (the host-independent stream the default-width fixtures regenerate their
+    weights from): fixed bit patterns (integer hashing + one fp32 multiply: the same on every host), the recipe's statistics, and the
+    independence of streams / seeds / chunk boundaries."""
+    from trajectorycrafter_amd import init_weights as iw
+    x = iw.hashed_normal((2, 5), 3, 5)
+    assert x.view(torch.int32).flatten().tolist() == [1038109939, 1069986748, 1069251804, -1086144235, 1066918607, -1078836870,
+                                                      -1093203958, 1059999443, -1081601279, -1085032175]
+    sd = iw.hashed_state_dict({"a.weight": (4, 6), "norm.weight": (6,), "b.bias": (5,)}, 9)
+    assert iw.state_dict_digest(sd) == "7afc28ea34d0f60477ece4b9d7a0d892679ebf4933ccace851291682b126cf66"
+    assert all(torch.equal(v, v.to(torch.bfloat16).float()) for v in sd.values())          # bf16-representable
+    assert abs(float(sd["norm.weight"].mean()) - 1.0) < 0.2 and float(sd["b.bias"].abs().max()) < 0.1
+    big = iw.hashed_normal((1 << 20,), 1, 2)
+    assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1.0) < 5e-3 and 3.0 < float(big.abs().max()) <= 3.4642
+    # element i does not depend on how the tensor is chunked or shaped; streams and seeds differ
+    n = (1 << 24) + 7
+    long = iw.hashed_normal((n,), 1, 2)
+    assert torch.equal(long[:1 << 20], big) and torch.equal(iw.hashed_normal((7, 3), 1, 2).flatten(), big[:21])
+    assert not torch.equal(iw.hashed_normal((64,), 1, 3), big[:64]) and not torch.equal(iw.hashed_normal((64,), 2, 2), big[:64])
+    assert torch.equal(iw.hashed_normal((4,), 1, 2, scale=0.5), big[:4] * 0.5)

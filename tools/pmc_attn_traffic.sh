@@ -1,11 +1,12 @@
-# HBM-side traffic of the self-attention launch as the product issues it (bound proven, tail split; 32x32x16 body and the optional
-# 16x16x32 body): FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes, no trace domains (MI355X_MICROARCH.md, HBM).
+# HBM-side traffic of the attention launches as the product issues them (tools/attn_launch.py: self-attention <64> bound proven + tail
+# split on the fused-QKV layout, cross-attention <128>): FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes, no trace domains
+# (MI355X_MICROARCH.md, HBM).
 # usage (GPU box): bash tools/pmc_attn_traffic.sh <tag>   -> gpurun_out/<tag>_attn_pmc.json
-tag=${1:-r3}
+tag=${1:-r4}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 250 rocprofv3 --pmc $ctr --output-format csv -d $R/gpurun_out/${tag}_pmc_attn_$ctr -- python3 $R/tools/attn_body_bench.py 2 1 > $R/gpurun_out/${tag}_pmc_attn_$ctr.log 2>&1 || exit 1
+  timeout -k 10 250 rocprofv3 --pmc $ctr --output-format csv -d $R/gpurun_out/${tag}_pmc_attn_$ctr -- python3 $R/tools/attn_launch.py 3 > $R/gpurun_out/${tag}_pmc_attn_$ctr.log 2>&1 || exit 1
 done
 cd $R
 python3 - "$tag" <<'PY'
@@ -19,7 +20,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             if r["Counter_Name"] == ctr and ("attn_fwd" in r["Kernel_Name"] or "attn_combine" in r["Kernel_Name"]):
                 n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
                 per[n[:n.index("(")] if "(" in n else n][ctr].append(float(r["Counter_Value"]))
-out = {"collection": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes, no trace domains, tools/attn_body_bench.py 2 1 ([2,17776,48,64], product flags)",
+out = {"collection": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes, no trace domains, tools/attn_launch.py 3 (self [2,17776,48,64] fused-QKV layout + cross [2,17550|4050,16,128], product flags)",
        "gfx950_correction": "read bytes = 2 x FETCH_SIZE x 1024 (128-B requests tallied at 64 B); WRITE_SIZE exact for 16-B-per-lane stores",
        "algorithmic_bytes_per_launch": 4 * 2 * 17776 * 48 * 64 * 2, "kernels": {}}
 for k, v in per.items():
