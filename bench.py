@@ -249,7 +249,7 @@ def cpu_baseline_bounded(args):
 class DataPlane:
     """State of the data-plane collective (the one all-gather per clip) and the rules for leaving RCCL.
 
-    Every RCCL call runs as a *stage*: on a guard thread (`dp.guarded`, bounded by TCX_RCCL_GUARD_S, default 60 s), followed by a
+    Every RCCL call runs as a *stage*: on a guard thread (`dp.guarded`, bounded by TCX_RCCL_GUARD_S, default 90 s), followed by a
     MIN vote over the gloo control group, so all ranks keep RCCL or all fall back to the host-staged gloo gather together — a rank
     that fails or hangs early never leaves the others inside an RCCL call.  The fallback is LOUD (stderr + `collective_fallback`
     in the JSON line); TCX_BENCH_RCCL_FATAL=1 turns it into exit code 3."""
@@ -257,7 +257,7 @@ class DataPlane:
     def __init__(self, rank: int, local: int, backend: str):
         self.rank, self.local, self.backend = rank, local, backend
         self.group, self.error, self.abandoned = None, None, 0
-        self.guard_s = float(os.environ.get("TCX_RCCL_GUARD_S", 60.0))
+        self.guard_s = float(os.environ.get("TCX_RCCL_GUARD_S", 90.0))
 
     def vote(self, err) -> bool:
         import torch
@@ -394,7 +394,11 @@ def run_rank(args):
         dist.all_gather_object(devices, mine)                            # gloo: who runs where, printed in config.ranks
         if plane.backend == "nccl":
             # separately voted stages: (1) communicator group creation, (2) a one-element all-reduce
-            plane.group = plane.stage(lambda: dist.new_group(backend="nccl", timeout=dp.dist_timeout()), "new_group(nccl)")
+            # The RCCL group's own timeout is LONG on purpose: the bound on a stuck call is the guard (90 s).  torch's NCCL watchdog
+            # tears the whole process down when a collective exceeds the group timeout — with 120 s it would kill this rank half a
+            # minute after the guard had already declared the call hung and the ranks had fallen back, before the flagged JSON line
+            # is printed.  (The product runner has no fallback and keeps the 120 s: there an abort IS the wanted outcome.)
+            plane.group = plane.stage(lambda: dist.new_group(backend="nccl", timeout=dp.dist_timeout(1800.0)), "new_group(nccl)")
         if plane.backend == "nccl":
             def probe():
                 one = torch.ones(1, device=device)
