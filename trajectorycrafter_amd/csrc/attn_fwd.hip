@@ -490,11 +490,17 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 
     // Software pipeline over 64-key tiles; staging and synchronisation in rounds of TPB tiles ("super-steps").
     // Tile t lives in ring slot t % R of its operand.  At the start of the super-step of tiles t0 .. t0+TPB-1 the
-    // ring holds K[t0+1 .. t0+TPB] and V[t0 .. t0+TPB-1]; the super-step issues the global loads of
-    // K[t0+TPB+1 .. t0+2TPB] and V[t0+TPB .. t0+2TPB-1] at its top, runs its tiles (tile t: S(t+1) from K[t+1]
-    // interleaved with softmax/PV of tile t from V[t]), then writes the loaded tiles into the slots their
-    // predecessors have just vacated, and ends with the only barrier.  PH = t0 % R is a template constant, so
-    // every LDS address is base register + immediate.
+    // ring holds K[t0+1 .. t0+TPB] and V[t0 .. t0+TPB-1] and the staging registers hold (or are about to receive)
+    // K[t0+TPB+1 .. t0+2TPB] and V[t0+TPB .. t0+2TPB-1], requested one super-step ago.  The super-step FIRST writes
+    // those registers into the slots whose tiles the previous super-step finished with (every wave is past the
+    // barrier that ended it), re-issues the registers' loads two rounds ahead (K[t0+2TPB+1 ..], V[t0+2TPB ..]), runs
+    // its tiles (tile t: S(t+1) from K[t+1] interleaved with softmax/PV of tile t from V[t]) and ends with the only
+    // barrier, which publishes the tiles written at its top for the next super-step.  Writing at the TOP (round 4,
+    // D = 64) instead of just before the barrier takes the ds_writes and their completion wait out of the barrier's
+    // shadow.  D = 128 keeps the round-1 order — loads at the top, writes just before the barrier: its
+    // staging registers would otherwise live across the barrier and the kernel (245 VGPRs) spills.  PH = t0 % R is a
+    // template constant, so every LDS address is base register + immediate.
+    constexpr bool WRITE_AT_TOP = D == 64;
     constexpr std::integral_constant<int, 0> J0{};
     constexpr std::integral_constant<int, TPB - 1> J1{};
     f32x16 sa[2], sb[2];
@@ -514,11 +520,21 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     };
     auto super_step = [&](auto bnd, auto masked, auto ph, int t0) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph)::value;
-        load_k(J0, t0 + TPB + 1);
-        load_v(J0, t0 + TPB);
+        auto write_staged = [&]() __attribute__((always_inline)) {     // K[t0+TPB+1 ..], V[t0+TPB ..] into the slots of finished tiles
+            write_k(J0, (PH + TPB + 1) % R);
+            write_v(J0, (PH + TPB) % R);
+            if constexpr (TPB == 2) {
+                write_k(J1, (PH + TPB + 2) % R);
+                write_v(J1, (PH + TPB + 1) % R);
+            }
+        };
+        constexpr int AHEAD = WRITE_AT_TOP ? 2 * TPB : TPB;
+        if constexpr (WRITE_AT_TOP) write_staged();           // loaded a super-step ago
+        load_k(J0, t0 + AHEAD + 1);
+        load_v(J0, t0 + AHEAD);
         if constexpr (TPB == 2) {
-            load_k(J1, t0 + TPB + 2);
-            load_v(J1, t0 + TPB + 1);
+            load_k(J1, t0 + AHEAD + 2);
+            load_v(J1, t0 + AHEAD + 1);
         }
         if constexpr (TPB == 2) {
             // the second tile's K slot ((PH + 2) % R) is resident for the whole super-step: its first fragments are prefetched
@@ -530,12 +546,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             if constexpr (PH == 0) one_tile(bnd, masked, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t0, sa, sb, std::false_type{}, nullptr);
             else one_tile(bnd, masked, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t0, sb, sa, std::false_type{}, nullptr);
         }
-        write_k(J0, (PH + TPB + 1) % R);
-        write_v(J0, (PH + TPB) % R);
-        if constexpr (TPB == 2) {
-            write_k(J1, (PH + TPB + 2) % R);
-            write_v(J1, (PH + TPB + 1) % R);
-        }
+        if constexpr (!WRITE_AT_TOP) write_staged();          // loaded at this super-step's top
         __syncthreads();
     };
     // tiles left after the last full super-step: fewer than TPB steps with a successor (everything they read is
@@ -578,7 +589,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     qk_part(kbuf0, sa, 0, KS);
     if (ntiles == 1 && (Sk & 63)) mask_tail(sa);
     if constexpr (!bounded) row_max_and_rescale(sa);
-    __syncthreads();                      // slot 0 of K is overwritten at the end of the first super-step
+    __syncthreads();                      // slot 0 of K is overwritten at the top of the first super-step
+    if constexpr (WRITE_AT_TOP) {          // what the first super-step writes at its top
+        load_k(J0, TPB + 1);
+        load_v(J0, TPB);
+        if constexpr (TPB == 2) {
+            load_k(J1, TPB + 2);
+            load_v(J1, TPB + 1);
+        }
+    }
 
     auto run = [&](auto bnd) __attribute__((always_inline)) {
         int t0 = 0;
