@@ -23,11 +23,17 @@ open(p, "w").write(pre + s + post)
 print("wait probe applied to", p)
 
 # ---- -DTCX_EXP_2SETS (D = 64 / TPB = 2 only; correct results) ----
+# Written against the staging order BEFORE "write at the top" (commit 7d1a0b1 and earlier: loads at a super-step's top, writes just
+# before its barrier).  The shipped kernel has since adopted what this probe led to; on a newer tree only the wait-only probe applies.
 full = open(p).read()
 pre, s, post = full[:full.index("__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p)")], None, None
 a = full.index("__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p)")
 b = full.index("// ---- the bound-centred D = 64 loop on v_mfma_f32_16x16x32_bf16")
 pre, s, post = full[:a], full[a:b], full[b:]
+if "load_k(J0, t0 + TPB + 1);\n        load_v(J0, t0 + TPB);" not in s:
+    print("2SETS probe skipped: this tree already stages at the top of the super-step (the probe recorded in "
+          "profiles/r4_attn8_wait_probe.txt was run on commit 7d1a0b1)")
+    sys.exit(0)
 rep("    u32x4 kreg[TPB][NLD], vreg[TPB][NLD];\n",
     "    u32x4 kreg[TPB][NLD], vreg[TPB][NLD];\n#ifdef TCX_EXP_2SETS\n    u32x4 kreg2[TPB][NLD], vreg2[TPB][NLD];\n#endif\n")
 old = s[s.index("        constexpr int PH = decltype(ph)::value;\n        load_k(J0, t0 + TPB + 1);\n        load_v(J0, t0 + TPB);\n"):s.index("        if constexpr (TPB == 2) {\n            // the second tile's K slot ((PH + 2) % R) is resident")]

@@ -6,7 +6,8 @@
 R=$GRAFT_REPO_ROOT
 [ -f $R/.waitprobe ] || { python3 $R/tools/exp/attn8_wait_probe.py $R/trajectorycrafter_amd/csrc/attn_fwd.hip && touch $R/.waitprobe; } || exit 1
 {
-for f in "" "-DTCX_EXP_WAITONLY" "-DTCX_EXP_2SETS" "" "-DTCX_EXP_2SETS"; do
+grep -q TCX_EXP_2SETS $R/trajectorycrafter_amd/csrc/attn_fwd.hip && SETS="-DTCX_EXP_2SETS" || SETS=""      # the 2SETS probe only exists on trees before write-at-top
+for f in "" "-DTCX_EXP_WAITONLY" $SETS "" $SETS; do
   echo "=== ${f:-shipped}"
   bash $R/tools/exp/attn_stamps.sh "$f" 8 3 2>&1 | grep "body 32 wave\|median:"
 done

@@ -5,11 +5,14 @@
 cd $GRAFT_REPO_ROOT/trajectorycrafter_amd/csrc
 python3 - <<'PY'
 s = open("attn_fwd.hip").read()
-s = s.replace("""#ifndef TCX_EXP_NOWRITE
-        write_k(J0, (PH + TPB + 1) % R);""", """        const long long tA = clock64();
+# round 4: the staged tiles are written at the TOP of a super-step (D = 64) — stamp that segment and the barrier at its end
+s = s.replace("""        if constexpr (WRITE_AT_TOP) write_staged();           // loaded a super-step ago
+""", """        const long long tA = clock64();
         __builtin_amdgcn_sched_barrier(0);
-#ifndef TCX_EXP_NOWRITE
-        write_k(J0, (PH + TPB + 1) % R);""")
+        if constexpr (WRITE_AT_TOP) write_staged();           // loaded a super-step ago
+        __builtin_amdgcn_sched_barrier(0);
+        st_write += clock64() - tA;
+""")
 s = s.replace("""#ifndef TCX_EXP_NOBARRIER
         __syncthreads();
 #endif
@@ -18,9 +21,7 @@ s = s.replace("""#ifndef TCX_EXP_NOBARRIER
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
-        const long long tC = clock64();
-        st_write += tB - tA;
-        st_bar += tC - tB;
+        st_bar += clock64() - tB;
         st_n += 1;
     };""")
 s = s.replace("    auto run = [&](auto bnd) __attribute__((always_inline)) {", "    const long long tRun0 = clock64();\n    auto run = [&](auto bnd) __attribute__((always_inline)) {")
@@ -34,5 +35,5 @@ assert s.count("st_write") >= 3
 open("/tmp/attn_stamp.hip", "w").write(s)
 PY
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -w -I. -x hip -c /tmp/attn_stamp.hip -o /tmp/attn_s.o && \
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libtcx_s.so tcx_api.o /tmp/attn_s.o norm.o elementwise.o conv.o groupnorm.o warp.o gemm.o && \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libtcx_s.so tcx_api.o /tmp/attn_s.o norm.o elementwise.o conv.o conv_mfma.o groupnorm.o warp.o gemm.o && \
 TCX_LIB=/tmp/libtcx_s.so python3 $GRAFT_REPO_ROOT/tools/microbench.py attn --iters 1 2>&1 | grep "STAMP" | sort | uniq -c | sort -rn | head -8
