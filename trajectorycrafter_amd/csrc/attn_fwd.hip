@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     // resident (first tile of a super-step): otherwise every tile starts by waiting one LDS round trip for them
     bf16x8 kfa[2], kfb[2];
     auto tile_body_fine = [&](auto has_next, auto prefetched, const char* kb, const char* kb_after, const char* vb, f32x16 (&cur)[2],
-                              f32x16 (&nxt)[2]) __attribute__((always_inline)) {
+                              f32x16 (&nxt)[2], auto stg) __attribute__((always_inline)) {
         constexpr bool NEXT = decltype(has_next)::value, PRE = decltype(prefetched)::value;
         auto read_k_from = [&](const char* base, int st, bf16x8 (&kf)[2]) __attribute__((always_inline)) {
 #pragma unroll
@@ -483,9 +483,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             vprev[1] = vcur[1];
         };
         step(0, kfa, kfb);
+        stg(std::integral_constant<int, 0>{});
         step(1, kfb, kfa);
+        stg(std::integral_constant<int, 1>{});
         step(2, kfa, kfb);
+        stg(std::integral_constant<int, 2>{});
         step(3, kfb, kfa);
+        stg(std::integral_constant<int, 3>{});
     };
 
     // Software pipeline over 64-key tiles; staging and synchronisation in rounds of TPB tiles ("super-steps").
@@ -495,9 +499,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     // those registers into the slots whose tiles the previous super-step finished with (every wave is past the
     // barrier that ended it), re-issues the registers' loads two rounds ahead (K[t0+2TPB+1 ..], V[t0+2TPB ..]), runs
     // its tiles (tile t: S(t+1) from K[t+1] interleaved with softmax/PV of tile t from V[t]) and ends with the only
-    // barrier, which publishes the tiles written at its top for the next super-step.  Writing at the TOP (round 4,
-    // D = 64) instead of just before the barrier takes the ds_writes and their completion wait out of the barrier's
-    // shadow.  D = 128 keeps the round-1 order — loads at the top, writes just before the barrier: its
+    // barrier, which publishes the tiles written during it for the next super-step.  Writing EARLY in the super-step
+    // (round 4, D = 64; spread over its steps, see SPREAD below) instead of just before the barrier takes the ds_writes
+    // and their completion wait out of the barrier's shadow.  D = 128 keeps the round-1 order — loads at the top, writes just before the barrier: its
     // staging registers would otherwise live across the barrier and the kernel (245 VGPRs) spills.  PH = t0 % R is a
     // template constant, so every LDS address is base register + immediate.
     constexpr bool WRITE_AT_TOP = D == 64;
@@ -507,10 +511,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     // MASK: this tile may compute the scores of the LAST key tile (ragged Sk).  The steady-state loop is instantiated with
     // MASK = false: hipcc if-converts `if (last) mask_tail(nxt)` into 32 v_cndmask + the predicate arithmetic executed on EVERY
     // tile (18 % of the issue cycles of this issue-bound loop); only the <= 2 super-steps before the end carry the check.
+    auto no_stg = [](auto) __attribute__((always_inline)) {};
     auto one_tile = [&](auto bnd, auto masked, auto slot_k, auto slot_v, int tile, f32x16 (&cur)[2], f32x16 (&nxt)[2], auto prefetched,
-                        const char* kb_after) __attribute__((always_inline)) {
+                        const char* kb_after, auto stg) __attribute__((always_inline)) {
         if constexpr (FINE) tile_body_fine(std::true_type{}, prefetched, kbuf0 + decltype(slot_k)::value * TILEB, kb_after,
-                                           vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
+                                           vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt, stg);
         else tile_body(std::true_type{}, kbuf0 + decltype(slot_k)::value * TILEB, vbuf0 + decltype(slot_v)::value * TILEB, cur, nxt);
         if constexpr (decltype(masked)::value) {
             if (tile + 1 == ntiles - 1 && (Sk & 63)) mask_tail(nxt);
@@ -529,22 +534,55 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             }
         };
         constexpr int AHEAD = WRITE_AT_TOP ? 2 * TPB : TPB;
-        if constexpr (WRITE_AT_TOP) write_staged();           // loaded a super-step ago
-        load_k(J0, t0 + AHEAD + 1);
-        load_v(J0, t0 + AHEAD);
-        if constexpr (TPB == 2) {
-            load_k(J1, t0 + AHEAD + 2);
-            load_v(J1, t0 + AHEAD + 1);
+        constexpr bool SPREAD = WRITE_AT_TOP && FINE && TPB == 2;
+        // SPREAD (the fine D = 64 loop): the four staged pieces (K J0, V J0, K J1, V J1) do not move in one burst at the top but one at
+        // a time, each written and its registers re-loaded behind steps 0 and 2 of the super-step's two tiles: a burst of 4 x 8
+        // ds_write_b128 right behind the barrier holds the LDS port for 256 cycles while all eight waves want their first
+        // fragments (stand-alone 6.88 -> 6.80 ms for all four behind the first tile's steps, 6.70 ms spread over both tiles; one
+        // instruction behind every step, write and load apart, 6.73: DESIGN §3.1)
+        auto piece = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value;
+            if constexpr (I == 0) { write_k(J0, (PH + TPB + 1) % R); load_k(J0, t0 + AHEAD + 1); }
+            else if constexpr (I == 1) { write_v(J0, (PH + TPB) % R); load_v(J0, t0 + AHEAD); }
+            else if constexpr (I == 2) { write_k(J1, (PH + TPB + 2) % R); load_k(J1, t0 + AHEAD + 2); }
+            else { write_v(J1, (PH + TPB + 1) % R); load_v(J1, t0 + AHEAD + 1); }
+        };
+        auto spread = [&](auto ic) __attribute__((always_inline)) {      // first tile: pieces 0, 1 behind steps 0, 2
+            constexpr int I = decltype(ic)::value;
+            if constexpr (I == 0) piece(std::integral_constant<int, 0>{});
+            else if constexpr (I == 2) piece(std::integral_constant<int, 1>{});
+        };
+        auto spread_b = [&](auto ic) __attribute__((always_inline)) {    // second tile: pieces 2, 3 behind steps 0, 2
+            constexpr int I = decltype(ic)::value;
+            if constexpr (I == 0) piece(std::integral_constant<int, 2>{});
+            else if constexpr (I == 2) piece(std::integral_constant<int, 3>{});
+        };
+        if constexpr (!SPREAD) {
+            if constexpr (WRITE_AT_TOP) write_staged();           // loaded a super-step ago
+            load_k(J0, t0 + AHEAD + 1);
+            load_v(J0, t0 + AHEAD);
+            if constexpr (TPB == 2) {
+                load_k(J1, t0 + AHEAD + 2);
+                load_v(J1, t0 + AHEAD + 1);
+            }
         }
         if constexpr (TPB == 2) {
             // the second tile's K slot ((PH + 2) % R) is resident for the whole super-step: its first fragments are prefetched
-            one_tile(bnd, masked, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb, std::false_type{},
-                     kbuf0 + ((PH + 2) % R) * TILEB);
-            one_tile(bnd, masked, std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa, std::true_type{},
-                     nullptr);
+            if constexpr (SPREAD)
+                one_tile(bnd, masked, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb, std::false_type{},
+                         kbuf0 + ((PH + 2) % R) * TILEB, spread);
+            else
+                one_tile(bnd, masked, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb, std::false_type{},
+                         kbuf0 + ((PH + 2) % R) * TILEB, no_stg);
+            if constexpr (SPREAD)
+                one_tile(bnd, masked, std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa, std::true_type{},
+                         nullptr, spread_b);
+            else
+                one_tile(bnd, masked, std::integral_constant<int, (PH + 2) % R>{}, std::integral_constant<int, (PH + 1) % R>{}, t0 + 1, sb, sa, std::true_type{},
+                         nullptr, no_stg);
         } else {
-            if constexpr (PH == 0) one_tile(bnd, masked, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t0, sa, sb, std::false_type{}, nullptr);
-            else one_tile(bnd, masked, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t0, sb, sa, std::false_type{}, nullptr);
+            if constexpr (PH == 0) one_tile(bnd, masked, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t0, sa, sb, std::false_type{}, nullptr, no_stg);
+            else one_tile(bnd, masked, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t0, sb, sa, std::false_type{}, nullptr, no_stg);
         }
         if constexpr (!WRITE_AT_TOP) write_staged();          // loaded at this super-step's top
         __syncthreads();
@@ -556,11 +594,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         const int rem = (ntiles - 1) - t0;                   // 0 .. TPB-1
         if constexpr (TPB == 2) {
             if (rem == 1) {
-                one_tile(bnd, std::true_type{}, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb, std::false_type{}, nullptr);
-                if constexpr (FINE) tile_body_fine(std::false_type{}, std::false_type{}, kbuf0, nullptr, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
+                one_tile(bnd, std::true_type{}, std::integral_constant<int, (PH + 1) % R>{}, std::integral_constant<int, PH % R>{}, t0, sa, sb, std::false_type{}, nullptr, no_stg);
+                if constexpr (FINE) tile_body_fine(std::false_type{}, std::false_type{}, kbuf0, nullptr, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa, no_stg);
                 else tile_body(std::false_type{}, kbuf0, vbuf0 + ((PH + 1) % R) * TILEB, sb, sa);
             } else {
-                if constexpr (FINE) tile_body_fine(std::false_type{}, std::false_type{}, kbuf0, nullptr, vbuf0 + (PH % R) * TILEB, sa, sb);
+                if constexpr (FINE) tile_body_fine(std::false_type{}, std::false_type{}, kbuf0, nullptr, vbuf0 + (PH % R) * TILEB, sa, sb, no_stg);
                 else tile_body(std::false_type{}, kbuf0, vbuf0 + (PH % R) * TILEB, sa, sb);
             }
         } else {
