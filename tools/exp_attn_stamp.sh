@@ -1,5 +1,6 @@
-# In-kernel cycle stamps (s_memtime) of the shipped attention loop: loop total, LDS-write segment, barrier wait, for
-# waves 0 and 7 of two workgroups.  Patches a COPY of attn_fwd.hip; timing-only build.  Usage on the GPU box:
+# In-kernel cycle stamps (s_memtime) of the shipped attention loop: loop total, barrier wait (and, for the kernels that still write
+# their staged tiles in one segment — D = 128 and the coarse loops; the fine D = 64 loop spreads them over its steps since round 4 —
+# that LDS-write segment), for waves 0 and 7 of two workgroups.  Patches a COPY of attn_fwd.hip; timing-only build.  Usage on the GPU box:
 #   bash tools/exp_attn_stamp.sh
 . "$(dirname "${BASH_SOURCE[0]}")/exp/with_experiments.sh" || exit 1     # patched scratch copy: the product sources carry no experiment switches
 cd $GRAFT_REPO_ROOT/trajectorycrafter_amd/csrc
