@@ -50,3 +50,20 @@ def vae_inputs():
     z = bf16r(iw.hashed_normal(VAE_Z, IN_SEED, 10))
     video = bf16r((iw.hashed_normal(VAE_VIDEO, IN_SEED, 11) * 0.4).clamp(-1.0, 1.0))   # in [-1, 1] like normalised frames; exact IEEE ops only
     return dict(z=z, video=video)
+
+
+PIPE_GLOBAL_SEED = 177                   # the reference draws the reference-latent posterior sample from the GLOBAL rng (:886)
+
+
+def pipeline_inputs():
+    """9 frames 32x48 (latent [1,3,16,4,6]): video / reference in [0, 1], a blocky 0 / 255 mask (first frame unmasked), prompt
+    embeddings at the 5B text width, seeded noise — all from the host-independent stream, bf16-representable where they are cast."""
+    Fv, H, W = 9, 32, 48
+    video = (iw.hashed_normal((1, 3, Fv, H, W), IN_SEED, 20) * 0.25 + 0.5).clamp(0.0, 1.0)
+    blocks = (iw.hashed_normal((1, 1, Fv, H // 8, W // 8), IN_SEED, 21) > 0.5).float()
+    mask = blocks.repeat_interleave(8, 3).repeat_interleave(8, 4) * 255.0
+    mask[:, :, 0] = 0
+    return dict(video=video, mask_video=mask, reference=video[:, :, :5].clone(),
+                prompt_embeds=bf16r(iw.hashed_normal((1, 226, 4096), IN_SEED, 22)),
+                negative_prompt_embeds=bf16r(iw.hashed_normal((1, 226, 4096), IN_SEED, 23)),
+                latents0=bf16r(iw.hashed_normal((1, 3, 16, H // 8, W // 8), IN_SEED, 24)))

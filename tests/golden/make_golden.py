@@ -652,7 +652,8 @@ def make_default():
          dict(config=repr(dc.DEFAULT_TR2), weights_digest=digest, weights=f"init_weights.hashed_state_dict(transformer_param_shapes(cfg), {dc.TR_SEED})",
               inputs="tests/golden/default_cases.transformer_inputs()", taps="block0 hidden / encoder [:, ::4, ::16]; cross0 [:, ::3, ::8]",
               source="reference CrossTransformer3DModel.forward (fp32, and .to(bfloat16) eager on the CPU) over tests/golden/diffusers_plain.py"))
-    del model, sd
+    del sd
+    model5b = model
 
     # ---- (a) default-width VAE ------------------------------------------------------------------------
     t0 = time.time()
@@ -682,7 +683,37 @@ def make_default():
          dict(config=repr(dc.DEFAULT_VAE), weights_digest=vdigest, weights=f"init_weights.hashed_state_dict(vae_param_shapes(cfg), {dc.VAE_SEED})",
               inputs="tests/golden/default_cases.vae_inputs()",
               source="reference AutoencoderKLCogVideoX.decode / .encode (fp32, and .to(bfloat16) eager on the CPU) over tests/golden/diffusers_plain.py"))
-    del vae, vsd
+    del vsd
+
+    # ---- (b + a) the whole pipeline at those widths: 2 CFG / DDIM steps + decode, 9 frames 32x48 ----------------------
+    pin = dc.pipeline_inputs()
+
+    def run_pipe_default(dt):
+        from oracle import diffusers_restated as dr_
+        m, v = model5b.to(dt), vae.to(dt)
+        pipe = ref_pl.TrajCrafter_Pipeline(tokenizer=None, text_encoder=None, vae=v, transformer=m,
+                                           scheduler=dp.DDIMSchedulerPlain(dr_.DDIMScheduler()))
+        kw = dict(prompt=None, negative_prompt=None, height=32, width=48, video=pin["video"], mask_video=pin["mask_video"],
+                  reference=pin["reference"], num_frames=9, num_inference_steps=2, guidance_scale=6.0,
+                  prompt_embeds=pin["prompt_embeds"].to(dt), negative_prompt_embeds=pin["negative_prompt_embeds"].to(dt))
+        with torch.no_grad():
+            torch.manual_seed(dc.PIPE_GLOBAL_SEED)
+            frames = pipe(latents=pin["latents0"].clone().to(dt), **kw).videos
+            torch.manual_seed(dc.PIPE_GLOBAL_SEED)
+            lat = pipe(latents=pin["latents0"].clone().to(dt), output_type="latent", return_dict=True, **kw).videos
+        return frames, lat
+
+    t0 = time.time()
+    pf32, pl32 = run_pipe_default(torch.float32)
+    pf16, pl16 = run_pipe_default(BF)
+    print(f"  default-width pipeline: fp32 + bf16 eager in {time.time() - t0:.1f} s; mean|frames bf16 - fp32| {float((pf16.float() - pf32.float()).abs().mean()):.3e}"
+          f"  latents {float((pl16.float() - pl32.float()).abs().mean()):.3e} (scale {float(pl32.float().abs().mean()):.3e})")
+    save("pipeline_default.safetensors",
+         dict(frames=pf32.float(), latents_out=pl32.float(), frames_bf16_eager=pf16.float(), latents_out_bf16_eager=pl16.to(BF)),
+         dict(tr_config=repr(dc.DEFAULT_TR2), vae_config=repr(dc.DEFAULT_VAE), steps=2, guidance_scale=6.0, global_seed=dc.PIPE_GLOBAL_SEED,
+              weights_digest_transformer=digest, weights_digest_vae=vdigest, inputs="tests/golden/default_cases.pipeline_inputs()",
+              source="reference TrajCrafter_Pipeline.__call__ (fp32, and every module .to(bfloat16) eager on the CPU) over tests/golden/diffusers_plain.py"))
+    del model5b, vae, model
 
     # ---- (c') the tiny pipeline: plain stand-ins reproduce the committed fp32 fixtures, then eager bf16 -------------
     tt, tv, tp = (load_file(os.path.join(HERE, n)) for n in ("transformer_tiny.safetensors", "vae_tiny.safetensors", "pipeline_tiny.safetensors"))

@@ -180,3 +180,44 @@ def test_vae_default_width_vs_reference_runs(golden, gpu, monkeypatch):
     _check_deep(post.mean, pc.mean, t["enc_mean"], what)
     _vs_reference_bf16(what, post.mean, pc.mean, t["enc_mean_bf16_eager"], t["enc_mean"])
     _check_deep(post.logvar, pc.logvar, t["enc_logvar"], "reference-run default-width VAE encode logvar")
+
+
+def test_pipeline_at_product_widths_vs_reference_runs(golden, gpu):
+    """The whole path at the widths the product dispatches on: `TrajCrafter_Pipeline.__call__` of the reference (conditioning from
+    pixels, 2 CFG / DDIM steps of the 2-layer 5B-geometry transformer, decode through the default-width VAE; fixture
+    pipeline_default.safetensors: fp32 and eager-bf16 runs) against the HIP pipeline.  Like tests/test_pipeline_gpu.py the
+    conditioning latents come from the oracle's VAE encoder (the reference samples the reference-frame posterior from the
+    GLOBAL rng), handed over as `inpaint_latents=` / `ref_latents=`; the HIP encoder itself is checked in the VAE test above."""
+    from oracle import pipeline as opl
+    from trajectorycrafter_amd.models.autoencoder_magvit import AutoencoderKLCogVideoX
+    from trajectorycrafter_amd.models.crosstransformer3d import CrossTransformer3DModel
+    from trajectorycrafter_amd.models.pipeline_trajectorycrafter import TrajCrafter_Pipeline
+    t, meta = golden("pipeline_default.safetensors")
+    tcfg, vcfg = ast.literal_eval(meta["tr_config"]), ast.literal_eval(meta["vae_config"])
+    tsd, vsd = dc.transformer_weights(), dc.vae_weights()
+    assert iw.state_dict_digest(tsd) == meta["weights_digest_transformer"] and iw.state_dict_digest(vsd) == meta["weights_digest_vae"]
+    x = dc.pipeline_inputs()
+    tr = CrossTransformer3DModel(**tcfg)
+    tr.load_state_dict(tsd, strict=True)
+    vae = AutoencoderKLCogVideoX(**vcfg)
+    vae.load_state_dict(vsd, strict=True)
+    pipe = TrajCrafter_Pipeline(None, None, vae.to(gpu, BF).eval(), tr.to(gpu, BF).eval())
+    torch.manual_seed(int(meta["global_seed"]))
+    inpaint, ref = opl.build_conditioning(vsd, vcfg, x["video"], x["mask_video"], x["reference"], 32, 48, "fp32")
+    kw = dict(prompt=None, height=32, width=48, num_frames=9, num_inference_steps=2, guidance_scale=6.0,
+              prompt_embeds=x["prompt_embeds"].to(BF), negative_prompt_embeds=x["negative_prompt_embeds"].to(BF),
+              latents=x["latents0"].to(BF), inpaint_latents=inpaint.to(BF), ref_latents=ref.to(BF))
+    lat = pipe(output_type="latent", **kw).videos
+    # the oracle's bf16 contract on the device (checker arithmetic; pinned on the CPU by tests/test_oracle_default.py)
+    tsg, vsg = {k: v.to(gpu) for k, v in tsd.items()}, {k: v.to(gpu) for k, v in vsd.items()}
+    g = lambda a: a.to(BF).float().to(gpu)
+    con_lat = opl.denoise(tsg, tcfg, g(x["latents0"]), g(x["prompt_embeds"]), g(x["negative_prompt_embeds"]), g(inpaint), g(ref),
+                          32, 48, 2, 6.0, prec="bf16")
+    what = "reference-run pipeline at product widths (2 CFG / DDIM steps, 2-layer 5B geometry)"
+    _check_deep(lat, con_lat, t["latents_out"], what + ": latents")
+    frames = pipe(**kw).videos
+    assert frames.shape == (1, 3, 9, 32, 48) and float(frames.min()) >= 0 and float(frames.max()) <= 1
+    con_frames = opl.decode_latents(vsg, vcfg, con_lat, prec="bf16")
+    _check_deep(frames, con_frames, t["frames"], what + ": frames (+ default-width VAE decode)")
+    _vs_reference_bf16(what + ": frames", frames, con_frames, t["frames_bf16_eager"], t["frames"])
+    assert torch.equal(pipe(**kw).videos, frames)

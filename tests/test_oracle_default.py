@@ -134,3 +134,38 @@ def test_tiny_pipeline_bf16_ref_models_the_reference_eager_bf16(golden):
               num_inference_steps=2, guidance_scale=6.0, num_frames=9)
     frames = opl.pipeline_call(w(tt), ast.literal_eval(mt["config"]), w(tv), ast.literal_eval(mv["config"]), prec="bf16_ref", **kw)
     check_bf16_model("tiny pipeline frames", frames, tb["frames_bf16_eager"], tp["frames"], lo=0.8, hi=1.25)
+
+
+@pytest.fixture(scope="module")
+def pipe_case(golden, tr_case, vae_case):
+    t, meta = golden("pipeline_default.safetensors")
+    _, tsd, tcfg, _ = tr_case
+    _, vsd, vcfg, _ = vae_case
+    assert meta["weights_digest_transformer"] == iw.state_dict_digest(tsd) and meta["weights_digest_vae"] == iw.state_dict_digest(vsd)
+    return t, int(meta["global_seed"]), tsd, tcfg, vsd, vcfg, dc.pipeline_inputs()
+
+
+def _pipe_kw(x):
+    return dict(prompt_embeds=x["prompt_embeds"], negative_prompt_embeds=x["negative_prompt_embeds"], video=x["video"],
+                mask_video=x["mask_video"], reference=x["reference"], height=32, width=48, latents=x["latents0"],
+                num_inference_steps=2, guidance_scale=6.0, num_frames=9)
+
+
+def test_pipeline_at_product_widths_fp32_matches_reference(pipe_case):
+    """`TrajCrafter_Pipeline.__call__` of the reference — conditioning from pixels (two VAE encodes), 2 CFG / DDIM steps of the
+    2-layer 5B-geometry transformer, decode through the default-width VAE — against the oracle's pipeline."""
+    t, seed, tsd, tcfg, vsd, vcfg, x = pipe_case
+    torch.manual_seed(seed)
+    lat = opl.pipeline_call(tsd, tcfg, vsd, vcfg, output_type="latent", **_pipe_kw(x))
+    _close(lat, t["latents_out"], rtol=1e-3, atol=1e-4)
+    torch.manual_seed(seed)
+    frames = opl.pipeline_call(tsd, tcfg, vsd, vcfg, **_pipe_kw(x))
+    _close(frames, t["frames"], rtol=1e-3, atol=1e-4)
+    assert frames.shape == (1, 3, 9, 32, 48) and float(frames.min()) >= 0 and float(frames.max()) <= 1
+
+
+def test_pipeline_at_product_widths_bf16_ref_models_the_reference_eager_bf16(pipe_case):
+    t, seed, tsd, tcfg, vsd, vcfg, x = pipe_case
+    torch.manual_seed(seed)
+    frames = opl.pipeline_call(tsd, tcfg, vsd, vcfg, prec="bf16_ref", **_pipe_kw(x))
+    check_bf16_model("default-width pipeline frames", frames, t["frames_bf16_eager"], t["frames"], lo=0.8, hi=1.25)
